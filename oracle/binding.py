@@ -1,0 +1,173 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product (abracadabra_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TF = 196608
+FIC_BITS = 9216
+CIF_BITS = 55296
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orx_create.restype = C.c_void_p
+        L.orx_create.argtypes = [C.c_int, C.c_int64, C.c_int]
+        L.orx_destroy.argtypes = [C.c_void_p]
+        L.orx_set_subch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orx_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.orx_get_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.orx_process.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        L.orx_cordic.restype = C.c_int32
+        L.orx_cordic.argtypes = [C.c_int64, C.c_int64]
+        L.orx_fft.argtypes = [C.c_void_p, C.c_void_p]
+        L.orx_viterbi.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orx_decode_linear.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.dab_tx_generate.argtypes = [C.c_void_p] * 4
+        L.dab_tx_msc_bytes_per_cif.argtypes = [C.c_void_p]
+        L.dab_crc16.restype = C.c_uint16
+        L.dab_crc16.argtypes = [C.c_void_p, C.c_int]
+        L.dab_conv_output.argtypes = [C.c_int, C.c_int]
+        L.dab_profile_eep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class TxCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("eid", C.c_int32), ("n_frames", C.c_int32), ("n_subch", C.c_int32),
+                ("delay", C.c_int32), ("loop", C.c_int32), ("fmt", C.c_int32), ("snr_db", C.c_double),
+                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("nseg", C.c_int), ("L", C.c_int * 4), ("PI", C.c_int * 4), ("n_in", C.c_int),
+                ("n_coded", C.c_int), ("n_cu", C.c_int)]
+
+
+SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("peak_idx", "<i4"),
+                       ("m_int", "<i4"), ("peak", "<f4"), ("total", "<f4"), ("cp_re", "<i8"), ("cp_im", "<i8")])
+assert SYNC_DTYPE.itemsize == 48
+
+
+def eep_profile(option, level, kbps):
+    p = Profile()
+    if lib().dab_profile_eep(option, level, kbps, C.byref(p)):
+        raise ValueError("invalid EEP profile")
+    return p
+
+
+def subch_layout(n=18, kbps=64, option=0, level=3):
+    """n equal sub-channels packed from CU 0: [[start_cu, option, level, kbps], …]"""
+    size = eep_profile(option, level, kbps).n_cu
+    return [[i * size, option, level, kbps] for i in range(n)]
+
+
+def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0, snr_db=30.0, cfo_hz=0.0,
+                rms=28.0):
+    """Synthetic Mode-I signal.  Returns (iq, fib[n_frames,12,32], msc[n_frames*4, bytes_per_cif])."""
+    L = lib()
+    cfg = TxCfg()
+    cfg.seed, cfg.eid, cfg.n_frames, cfg.n_subch = seed, eid, n_frames, len(subch)
+    cfg.delay, cfg.loop, cfg.fmt = delay, loop, fmt
+    cfg.snr_db, cfg.cfo_hz, cfg.rms = snr_db, cfo_hz, rms
+    for i, s in enumerate(subch):
+        for j in range(4):
+            cfg.subch[i][j] = int(s[j])
+    mb = L.dab_tx_msc_bytes_per_cif(C.byref(cfg))
+    if mb < 0:
+        raise ValueError("bad sub-channel configuration")
+    nsamp = delay + n_frames * TF
+    iq = np.zeros(nsamp * 2, dtype=np.int16 if fmt else np.uint8)
+    fib = np.zeros((n_frames, 12, 32), dtype=np.uint8)
+    msc = np.zeros((n_frames * 4, max(mb, 1)), dtype=np.uint8)
+    rc = L.dab_tx_generate(C.byref(cfg), iq.ctypes.data, fib.ctypes.data, msc.ctypes.data)
+    if rc:
+        raise RuntimeError(f"dab_tx_generate failed: {rc}")
+    return iq, fib, msc[:, :mb]
+
+
+class Stream:
+    """One oracle receiver instance (mirrors one stream of the dabx batch API)."""
+
+    def __init__(self, fmt=0, ring_len=16 * TF, subch=(), ti_slots=64):
+        self.L = lib()
+        self.h = self.L.orx_create(fmt, ring_len, ti_slots)
+        self.fmt = fmt
+        self.msc_bytes = 0
+        if len(subch):
+            self.set_subch(subch)
+
+    def close(self):
+        if self.h:
+            self.L.orx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_subch(self, subch):
+        a = np.ascontiguousarray(np.array(subch, dtype=np.int32).reshape(-1, 4))
+        rc = self.L.orx_set_subch(self.h, len(a), a.ctypes.data)
+        if rc < 0:
+            raise ValueError(f"orx_set_subch: {rc}")
+        self.msc_bytes = rc
+
+    def push(self, iq):
+        iq = np.ascontiguousarray(iq)
+        self.L.orx_push(self.h, iq.ctypes.data, iq.size // 2)
+
+    def state(self):
+        st = np.zeros(6, dtype=np.int64)
+        self.L.orx_get_state(self.h, st.ctypes.data)
+        return dict(pos=int(st[0]), inc=int(st[1]), locked=int(st[2]), cif=int(st[3]), bad=int(st[4]), wr=int(st[5]))
+
+    def process(self, n_frames, want_soft=True):
+        out = dict(
+            sync=np.zeros(n_frames, dtype=SYNC_DTYPE),
+            fic_soft=np.zeros((n_frames, FIC_BITS), dtype=np.int8) if want_soft else None,
+            msc_soft=np.zeros((n_frames, 4, CIF_BITS), dtype=np.int8) if want_soft else None,
+            fib=np.zeros((n_frames, 12, 32), dtype=np.uint8),
+            fib_ok=np.zeros((n_frames, 12), dtype=np.uint8),
+            msc=np.zeros((n_frames, 4, max(self.msc_bytes, 1)), dtype=np.uint8),
+            msc_valid=np.zeros((n_frames, 4), dtype=np.uint8),
+        )
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        rc = self.L.orx_process(self.h, n_frames, ptr(out["sync"]), ptr(out["fic_soft"]), ptr(out["msc_soft"]),
+                                ptr(out["fib"]), ptr(out["fib_ok"]), ptr(out["msc"]), ptr(out["msc_valid"]))
+        out["rc"] = rc
+        out["msc"] = out["msc"][:, :, :self.msc_bytes]
+        return out
+
+
+def fft(x):
+    """Oracle FFT of a complex64 vector of length 2048, natural bin order."""
+    re = np.ascontiguousarray(x.real.astype(np.float32))
+    im = np.ascontiguousarray(x.imag.astype(np.float32))
+    lib().orx_fft(re.ctypes.data, im.ctypes.data)
+    return re + 1j * im
+
+
+def decode_linear(soft, kind=0, option=0, level=3, kbps=64):
+    soft = np.ascontiguousarray(soft, dtype=np.int8)
+    out = np.zeros(8192, dtype=np.uint8)
+    n = lib().orx_decode_linear(kind, option, level, kbps, soft.ctypes.data, out.ctypes.data)
+    if n < 0:
+        raise ValueError("bad profile")
+    return out[:n].copy()

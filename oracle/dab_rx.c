@@ -1,0 +1,625 @@
+/*
+ * oracle/dab_rx.c — TEST INFRASTRUCTURE ONLY (checker, never the product).
+ *
+ * Scalar CPU restatement of the DAB Mode-I receive chain that the HIP library
+ * (abracadabra_amd/csrc) implements: null search, CP/PRS synchronisation,
+ * 2048-point FFT, pi/4-DQPSK demapping, frequency and time de-interleaving,
+ * depuncturing, K=7 Viterbi, energy de-dispersal and FIB CRC.
+ *
+ * PARITY UNPINNED.  The reference implements this chain only inside the closed
+ * binary lib/linux_x86_64/libdabsdr.so.4.0.1 (boundary: lib/linux_x86_64/
+ * dabsdr.h:397-429; caller src/radiocontrol.cpp:81-93).  There is no reference
+ * source, test or golden vector to follow, and the binary is not executed.
+ * The bit-level rules follow ETSI EN 300 401; the arithmetic contract (what
+ * "bit-exact" means for the float stages) is fixed in DESIGN.md §3: every
+ * float operation is a single IEEE-754 binary32 operation (no FMA
+ * contraction) in a stated order, so a GPU and a CPU evaluation agree bit for
+ * bit.  Build with -ffp-contract=off.
+ */
+#include "dab_spec.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NFFT 2048
+#define BACKOFF 24          /* FFT window starts this many samples inside the guard */
+#define MW 16               /* integer carrier-offset search range (kHz)            */
+#define SOFT_EXP 17         /* soft-bit scale exponent, see demap()                 */
+#define PM_INIT (-1000000)  /* path metric of states other than 0 at trellis start  */
+#define LOCK_THR 48.0f
+
+/* ------------------------------------------------------------------ tables */
+typedef struct {
+    float wr[NFFT], wi[NFFT];       /* W^k = exp(-j 2 pi k / 2048)                 */
+    float nhr[NFFT], nhi[NFFT];     /* NCO coarse: exp(+j 2 pi k / 2^11)           */
+    float nlr[NFFT], nli[NFFT];     /* NCO fine:   exp(+j 2 pi k / 2^22)           */
+    int8_t  prsq[NFFT];             /* PRS quadrant per bin, -1 unused             */
+    int8_t  prsdq[NFFT];            /* quadrant(P[k]) - quadrant(P[k-1]), -1 n/a   */
+    int16_t kofn[DAB_K];
+    int16_t n_of_bin[NFFT];         /* frequency de-interleaver, -1 unused         */
+    int16_t bin_of_pos[NFFT];       /* FFT output placement (digit reversal)       */
+    int16_t pos_of_bin[NFFT];
+    int16_t cfo_car[1534];          /* carriers k with k and k-1 both active       */
+    uint8_t prbs[DAB_CIF_BITS];
+    int ready;
+} tables_t;
+static tables_t T;
+
+static void tables_init(void)
+{
+    if (T.ready) return;
+    for (int k = 0; k < NFFT; k++) {
+        double a = 2.0 * M_PI * k / 2048.0;
+        T.wr[k] = (float)cos(a); T.wi[k] = (float)(-sin(a));
+        T.nhr[k] = (float)cos(a); T.nhi[k] = (float)sin(a);
+        double b = 2.0 * M_PI * k / 4194304.0;
+        T.nlr[k] = (float)cos(b); T.nli[k] = (float)sin(b);
+    }
+    dab_prs_quadrants(T.prsq);
+    dab_freq_interleaver(T.kofn);
+    memset(T.n_of_bin, -1, sizeof T.n_of_bin);
+    for (int n = 0; n < DAB_K; n++) T.n_of_bin[T.kofn[n] & 2047] = (int16_t)n;
+    for (int p = 0; p < NFFT; p++) {
+        int k1 = p >> 8, c = (p >> 5) & 7, f = (p >> 2) & 7, kk = p & 3;
+        int b = k1 + 8 * c + 64 * f + 512 * kk;
+        T.bin_of_pos[p] = (int16_t)b; T.pos_of_bin[b] = (int16_t)p;
+    }
+    int j = 0;
+    for (int b = 0; b < NFFT; b++) T.prsdq[b] = -1;
+    for (int k = -767; k <= 768; k++) {
+        if (k == 0 || k == 1) continue;
+        T.cfo_car[j++] = (int16_t)k;
+        T.prsdq[k & 2047] = (int8_t)((T.prsq[k & 2047] - T.prsq[(k - 1) & 2047]) & 3);
+    }
+    dab_prbs(T.prbs, DAB_CIF_BITS);
+    T.ready = 1;
+}
+
+/* ----------------------------------------------------- arithmetic contract */
+static inline void cmul(float ar, float ai, float br, float bi, float *yr, float *yi)
+{
+    float p0 = ar * br, p1 = ai * bi, p2 = ar * bi, p3 = ai * br;
+    *yr = p0 - p1; *yi = p2 + p3;
+}
+static inline void cmulc(float ar, float ai, float br, float bi, float *yr, float *yi)
+{   /* a * conj(b) */
+    float p0 = ar * br, p1 = ai * bi, p2 = ai * br, p3 = ar * bi;
+    *yr = p0 + p1; *yi = p2 - p3;
+}
+/* multiply by exp(-j q pi/2): exact */
+static inline void rotq(float xr, float xi, int q, float *yr, float *yi)
+{
+    switch (q & 3) {
+    case 0: *yr = xr;  *yi = xi;  break;
+    case 1: *yr = xi;  *yi = -xr; break;
+    case 2: *yr = -xr; *yi = -xi; break;
+    default:*yr = -xi; *yi = xr;  break;
+    }
+}
+
+/* fixed-order sum of 256 per-thread partials: xor butterfly inside each group
+ * of 64 (d = 1,2,4,8,16,32), then (W0+W1)+(W2+W3) */
+static float reduce256(const float *part)
+{
+    float p[256], q[256];
+    memcpy(p, part, sizeof p);
+    for (int d = 1; d < 64; d <<= 1) {
+        for (int i = 0; i < 256; i++) q[i] = p[i] + p[i ^ d];
+        memcpy(p, q, sizeof p);
+    }
+    float s01 = p[0] + p[64], s23 = p[128] + p[192];
+    return s01 + s23;
+}
+
+/* integer CORDIC: angle of (x + j y) in units of 2^-32 turn */
+static const int32_t cordic_tab[28] = {
+    536870912, 316933406, 167458907, 85004756, 42667331, 21354465, 10679838, 5340245, 2670163, 1335087,
+    667544, 333772, 166886, 83443, 41722, 20861, 10430, 5215, 2608, 1304, 652, 326, 163, 81, 41, 20, 10, 5};
+int32_t orx_cordic(int64_t y, int64_t x)
+{
+    if (x == 0 && y == 0) return 0;
+    uint64_t ax = (uint64_t)(x < 0 ? -x : x), ay = (uint64_t)(y < 0 ? -y : y), m = ax > ay ? ax : ay;
+    int sh = 0;
+    while ((m >> sh) >= (1ULL << 29)) sh++;
+    if (sh) { x >>= sh; y >>= sh; }             /* arithmetic shifts */
+    else while ((m << 1) < (1ULL << 29)) { m <<= 1; x *= 2; y *= 2; }
+    uint32_t ang = 0;
+    if (x < 0) { x = -x; y = -y; ang = 0x80000000u; }
+    for (int i = 0; i < 28; i++) {
+        int64_t xs = x >> i, ys = y >> i;
+        if (y > 0) { x += ys; y -= xs; ang += (uint32_t)cordic_tab[i]; }
+        else       { x -= ys; y += xs; ang -= (uint32_t)cordic_tab[i]; }
+    }
+    return (int32_t)ang;
+}
+
+/* NCO: exp(+j 2 pi theta / 2^32) from the two tables */
+static inline void nco(uint32_t th, float *cr, float *ci)
+{
+    unsigned hi = th >> 21, lo = (th >> 10) & 2047;
+    cmul(T.nhr[hi], T.nhi[hi], T.nlr[lo], T.nli[lo], cr, ci);
+}
+
+/* ----------------------------------------------------------------- the FFT */
+static inline void r4(float *r, float *i)
+{   /* natural-order 4-point DFT */
+    float p0r = r[0] + r[2], p0i = i[0] + i[2], p1r = r[0] - r[2], p1i = i[0] - i[2];
+    float q0r = r[1] + r[3], q0i = i[1] + i[3], tr = r[1] - r[3], ti = i[1] - i[3];
+    float q1r = ti, q1i = -tr;                           /* (u1-u3) * (-j) */
+    r[0] = p0r + q0r; i[0] = p0i + q0i; r[2] = p0r - q0r; i[2] = p0i - q0i;
+    r[1] = p1r + q1r; i[1] = p1i + q1i; r[3] = p1r - q1r; i[3] = p1i - q1i;
+}
+static inline void r8(float *r, float *i)
+{   /* natural-order 8-point DFT, decimation in frequency */
+    const float c8 = 0.70710678118654752440f;
+    float ar[4], ai[4], br[4], bi[4];
+    for (int j = 0; j < 4; j++) {
+        ar[j] = r[j] + r[j + 4]; ai[j] = i[j] + i[j + 4];
+        br[j] = r[j] - r[j + 4]; bi[j] = i[j] - i[j + 4];
+    }
+    float t0, t1;
+    t0 = br[1] + bi[1]; t1 = bi[1] - br[1]; br[1] = c8 * t0; bi[1] = c8 * t1;           /* * W8^1 */
+    t0 = br[2]; br[2] = bi[2]; bi[2] = -t0;                                             /* * W8^2 */
+    t0 = bi[3] - br[3]; t1 = br[3] + bi[3]; br[3] = c8 * t0; bi[3] = -(c8 * t1);        /* * W8^3 */
+    r4(ar, ai); r4(br, bi);
+    for (int m = 0; m < 4; m++) { r[2 * m] = ar[m]; i[2 * m] = ai[m]; r[2 * m + 1] = br[m]; i[2 * m + 1] = bi[m]; }
+}
+
+/* in place; result bin T.bin_of_pos[p] ends at position p */
+static void fft_pos(float *re, float *im)
+{
+    float vr[8], vi[8];
+    for (int t = 0; t < 256; t++) {                      /* pass A: stride 256, twiddle W^(t*c) */
+        for (int j = 0; j < 8; j++) { vr[j] = re[t + 256 * j]; vi[j] = im[t + 256 * j]; }
+        r8(vr, vi);
+        for (int c = 1; c < 8; c++) cmul(vr[c], vi[c], T.wr[t * c], T.wi[t * c], &vr[c], &vi[c]);
+        for (int c = 0; c < 8; c++) { re[t + 256 * c] = vr[c]; im[t + 256 * c] = vi[c]; }
+    }
+    for (int t = 0; t < 256; t++) {                      /* pass B: stride 32, twiddle W^(8*b*c) */
+        int base = (t >> 5) * 256 + (t & 31), b = t & 31;
+        for (int j = 0; j < 8; j++) { vr[j] = re[base + 32 * j]; vi[j] = im[base + 32 * j]; }
+        r8(vr, vi);
+        for (int c = 1; c < 8; c++) cmul(vr[c], vi[c], T.wr[8 * b * c], T.wi[8 * b * c], &vr[c], &vi[c]);
+        for (int c = 0; c < 8; c++) { re[base + 32 * c] = vr[c]; im[base + 32 * c] = vi[c]; }
+    }
+    for (int t = 0; t < 256; t++) {                      /* pass C: stride 4, twiddle W^(64*e*f) */
+        int base = (t >> 2) * 32 + (t & 3), e = t & 3;
+        for (int j = 0; j < 8; j++) { vr[j] = re[base + 4 * j]; vi[j] = im[base + 4 * j]; }
+        r8(vr, vi);
+        for (int f = 1; f < 8; f++) cmul(vr[f], vi[f], T.wr[64 * e * f], T.wi[64 * e * f], &vr[f], &vi[f]);
+        for (int f = 0; f < 8; f++) { re[base + 4 * f] = vr[f]; im[base + 4 * f] = vi[f]; }
+    }
+    for (int g = 0; g < 512; g++) r4(re + 4 * g, im + 4 * g);  /* pass D: radix 4 */
+}
+
+/* natural-order convenience wrapper (tests compare with numpy.fft) */
+void orx_fft(float *re, float *im)
+{
+    float tr[NFFT], ti[NFFT];
+    tables_init();
+    fft_pos(re, im);
+    for (int p = 0; p < NFFT; p++) { tr[T.bin_of_pos[p]] = re[p]; ti[T.bin_of_pos[p]] = im[p]; }
+    memcpy(re, tr, sizeof tr); memcpy(im, ti, sizeof ti);
+}
+
+/* ------------------------------------------------------------------ stream */
+typedef struct {
+    int32_t start_cu, option, level, kbps;
+    dab_profile_t prof;
+    uint32_t *stepinfo;
+    int nsteps, out_off;
+} subch_t;
+
+typedef struct {
+    int fmt;                    /* 0 = u8, 1 = s16 */
+    int64_t ring_len;           /* samples */
+    uint8_t *ring;
+    int64_t wr;                 /* samples pushed so far */
+    int64_t pos;                /* estimated start of the next frame's null symbol */
+    int32_t inc;                /* carrier offset, 2^-32 turn per sample */
+    int32_t locked, bad;
+    int64_t cif;                /* CIFs demodulated since lock */
+    int n_subch, msc_bytes;
+    subch_t sub[64];
+    int8_t *ti;                 /* [ti_slots][55296] time de-interleaver ring; a whole step of
+                                   frames is demodulated before any of it is decoded, so the ring
+                                   is deeper than the 16 CIFs of the interleaver: >= 15 + 4*frames */
+    int ti_slots;               /* power of two */
+    uint32_t fic_stepinfo[DAB_FIC_CW_IN + 6];
+} orx_t;
+
+typedef struct {                /* per-frame synchronisation record (same layout as dabx_sync_rec) */
+    int64_t t_sym0;             /* first sample of the PRS FFT window */
+    int32_t inc;
+    int32_t flags;              /* bit0 frame ok, bit1 wide search used */
+    int32_t peak_idx, m_int;
+    float peak, total;
+    int64_t cp_re, cp_im;
+} orx_sync_t;
+
+orx_t *orx_create(int fmt, int64_t ring_len, int ti_slots)
+{
+    tables_init();
+    orx_t *s = (orx_t *)calloc(1, sizeof *s);
+    s->fmt = fmt; s->ring_len = ring_len;
+    s->ring = (uint8_t *)calloc((size_t)ring_len, fmt ? 4 : 2);
+    s->ti_slots = ti_slots;
+    s->ti = (int8_t *)calloc((size_t)ti_slots, DAB_CIF_BITS);
+    dab_profile_t fp; dab_profile_fic(&fp);
+    dab_profile_stepinfo(&fp, s->fic_stepinfo);
+    return s;
+}
+void orx_destroy(orx_t *s)
+{
+    if (!s) return;
+    for (int i = 0; i < s->n_subch; i++) free(s->sub[i].stepinfo);
+    free(s->ti); free(s->ring); free(s);
+}
+int orx_set_subch(orx_t *s, int n, const int32_t *cfg)
+{
+    for (int i = 0; i < s->n_subch; i++) { free(s->sub[i].stepinfo); s->sub[i].stepinfo = NULL; }
+    s->n_subch = 0; s->msc_bytes = 0;
+    if (n < 0 || n > 64) return -1;
+    for (int i = 0; i < n; i++) {
+        subch_t *u = &s->sub[i];
+        u->start_cu = cfg[4 * i]; u->option = cfg[4 * i + 1]; u->level = cfg[4 * i + 2]; u->kbps = cfg[4 * i + 3];
+        if (dab_profile_eep(u->option, u->level, u->kbps, &u->prof)) return -2;
+        if (u->start_cu < 0 || u->start_cu + u->prof.n_cu > DAB_NCU) return -3;
+        u->stepinfo = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(u->prof.n_in + 8));
+        u->nsteps = dab_profile_stepinfo(&u->prof, u->stepinfo);
+        u->out_off = s->msc_bytes;
+        s->msc_bytes += u->prof.n_in / 8;
+    }
+    s->n_subch = n;
+    return s->msc_bytes;
+}
+void orx_push(orx_t *s, const void *iq, int64_t n)
+{
+    const int bps = s->fmt ? 4 : 2;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t w = (s->wr + i) % s->ring_len;
+        memcpy(s->ring + w * bps, (const uint8_t *)iq + i * bps, (size_t)bps);
+    }
+    s->wr += n;
+}
+void orx_get_state(const orx_t *s, int64_t *st)
+{
+    st[0] = s->pos; st[1] = s->inc; st[2] = s->locked; st[3] = s->cif; st[4] = s->bad; st[5] = s->wr;
+}
+
+static inline void sample(const orx_t *s, int64_t n, int32_t *i, int32_t *q)
+{
+    int64_t w = n % s->ring_len;
+    if (w < 0) w += s->ring_len;
+    if (s->fmt) { const int16_t *p = (const int16_t *)s->ring + 2 * w; *i = p[0]; *q = p[1]; }
+    else { const uint8_t *p = s->ring + 2 * w; *i = (int32_t)p[0] - 128; *q = (int32_t)p[1] - 128; }
+}
+
+/* -------- null search: 64-sample block energies, 41-block moving sum -------- */
+#define NS_BLOCKS 3072
+#define NS_WIN 41
+static int null_search(const orx_t *s, int64_t from, int64_t *null_start)
+{
+    uint64_t E[NS_BLOCKS + NS_WIN];
+    uint64_t tot = 0;
+    for (int b = 0; b < NS_BLOCKS + NS_WIN; b++) {
+        uint64_t e = 0;
+        for (int n = 0; n < 64; n++) {
+            int32_t i, q; sample(s, from + 64 * (int64_t)b + n, &i, &q);
+            e += (uint64_t)(i * i + q * q);
+        }
+        E[b] = e;
+        if (b < NS_BLOCKS) tot += e;
+    }
+    uint64_t best = ~0ULL; int bb = 0;
+    for (int b = 0; b < NS_BLOCKS; b++) {
+        uint64_t m = 0;
+        for (int j = 0; j < NS_WIN; j++) m += E[b + j];
+        if (m < best) { best = m; bb = b; }
+    }
+    /* the quietest window must be at least 6 dB below the average window */
+    if (!(best * 4 * NS_BLOCKS < tot * NS_WIN)) { *null_start = from; return 0; }
+    /* the null ends where two consecutive blocks rise above half the average
+     * block energy; the frame starts one null length before that edge */
+    int edge = bb + NS_WIN;
+    for (int b = bb; b + 1 < NS_BLOCKS + NS_WIN; b++)
+        if (E[b] * 2 * NS_BLOCKS > tot && E[b + 1] * 2 * NS_BLOCKS > tot) { edge = b; break; }
+    *null_start = from + 64 * (int64_t)edge - DAB_TNULL;
+    return 1;
+}
+
+/* window of 2048 samples starting at w0, de-rotated by -inc with phase 0 at
+ * sample `ref`; thread t handles n = t + 256 j with a step-256 recurrence */
+static void load_window(const orx_t *s, int64_t w0, int64_t ref, int32_t inc, float *re, float *im)
+{
+    uint32_t dth = (uint32_t)(-(int64_t)inc);
+    float sr, si;
+    nco(dth * 256u, &sr, &si);
+    for (int t = 0; t < 256; t++) {
+        float cr, ci;
+        nco(dth * (uint32_t)(w0 - ref + t), &cr, &ci);
+        for (int j = 0; j < 8; j++) {
+            int32_t i, q; sample(s, w0 + t + 256 * j, &i, &q);
+            if (j) cmul(cr, ci, sr, si, &cr, &ci);
+            cmul((float)i, (float)q, cr, ci, &re[t + 256 * j], &im[t + 256 * j]);
+        }
+    }
+}
+
+static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec)
+{
+    /* 1. guard-interval correlation over PRS + 3 FIC symbols (exact integers) */
+    int64_t cre = 0, cim = 0;
+    for (int sy = 0; sy < 4; sy++) {
+        int64_t g = pos_f + DAB_TNULL + (int64_t)sy * DAB_TS;
+        for (int n = 48; n < 456; n++) {
+            int32_t i1, q1, i2, q2;
+            sample(s, g + n, &i1, &q1); sample(s, g + n + DAB_TU, &i2, &q2);
+            cre += (int64_t)i1 * i2 + (int64_t)q1 * q2;
+            cim += (int64_t)q1 * i2 - (int64_t)i1 * q2;
+        }
+    }
+    int32_t A = orx_cordic(cim, cre);
+    int32_t inc_meas = (int32_t)((-(int64_t)A) >> 11);   /* |.| <= 2^20 */
+    int32_t inc;
+    if (wide) inc = inc_meas;
+    else {
+        int32_t d = (int32_t)(((uint32_t)(inc_meas - inc0) + (1u << 20)) & ((1u << 21) - 1)) - (1 << 20);
+        inc = inc0 + d;
+    }
+    float xr[NFFT], xi[NFFT], hr[NFFT], hi[NFFT], part[256];
+    int64_t w0 = pos_f + DAB_TNULL + DAB_TG - BACKOFF;
+    int m_best = 0;
+    load_window(s, w0, w0, inc, xr, xi);
+    fft_pos(xr, xi);
+    if (wide) {
+        /* 2. integer carrier offset: differential PRS correlation in frequency */
+        float best = -1.0f;
+        for (int m = -MW; m <= MW; m++) {
+            float pr[256], pi[256];
+            for (int t = 0; t < 256; t++) {
+                float ar = 0.0f, ai = 0.0f;
+                for (int i = 0; i < 6; i++) {
+                    int j = t + 256 * i;
+                    if (j >= 1534) break;
+                    int k = T.cfo_car[j], b1 = (k + m) & 2047, b0 = (k + m - 1) & 2047;
+                    int p1 = T.pos_of_bin[b1], p0 = T.pos_of_bin[b0];
+                    float dr, di, er, ei;
+                    cmulc(xr[p1], xi[p1], xr[p0], xi[p0], &dr, &di);
+                    rotq(dr, di, T.prsdq[k & 2047], &er, &ei);
+                    ar = ar + er; ai = ai + ei;
+                }
+                pr[t] = ar; pi[t] = ai;
+            }
+            float cr = reduce256(pr), ci = reduce256(pi);
+            float c0 = cr * cr, c1 = ci * ci, cm = c0 + c1;
+            if (cm > best) { best = cm; m_best = m; }
+        }
+        inc = inc_meas + m_best * (1 << 21);
+        load_window(s, w0, w0, inc, xr, xi);
+        fft_pos(xr, xi);
+    }
+    /* 3. fine timing: impulse response from the PRS */
+    for (int p = 0; p < NFFT; p++) {
+        int b = T.bin_of_pos[p];
+        float rr = 0.0f, ri = 0.0f;
+        if (T.prsq[b] >= 0) rotq(xr[p], xi[p], T.prsq[b], &rr, &ri);
+        hr[b] = rr; hi[b] = -ri;                       /* conj(R) in natural order */
+    }
+    fft_pos(hr, hi);
+    float peak = -1.0f; int pidx = 0;
+    for (int t = 0; t < 256; t++) {
+        float acc = 0.0f;
+        for (int e = 0; e < 8; e++) {
+            int p = 8 * t + e;
+            float a = hr[p] * hr[p], b = hi[p] * hi[p], m2 = a + b;
+            acc = acc + m2;
+            int n = T.bin_of_pos[p];
+            if (m2 > peak || (m2 == peak && n < pidx)) { peak = m2; pidx = n; }
+        }
+        part[t] = acc;
+    }
+    float total = reduce256(part);
+    int delta = pidx >= 1024 ? pidx - 2048 : pidx;
+    rec->t_sym0 = w0 + delta - BACKOFF;
+    rec->inc = inc;
+    rec->flags = ((peak * 2048.0f >= LOCK_THR * total) ? 1 : 0) | (wide ? 2 : 0);
+    rec->peak_idx = pidx; rec->m_int = m_best;
+    rec->peak = peak; rec->total = total;
+    rec->cp_re = cre; rec->cp_im = cim;
+}
+
+/* demodulate the 76 symbols of one frame: FIC soft bits to fic[9216], MSC soft
+ * bits into the time de-interleaver ring slots (cif0 + c) & 15 */
+static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *fic)
+{
+    float pr[NFFT], pi[NFFT], xr[NFFT], xi[NFFT], yr[NFFT], yi[NFFT], part[256];
+    for (int l = 0; l < DAB_NSYM; l++) {
+        load_window(s, rec->t_sym0 + (int64_t)l * DAB_TS, rec->t_sym0, rec->inc, xr, xi);
+        fft_pos(xr, xi);
+        if (l > 0) {
+            for (int t = 0; t < 256; t++) {
+                float acc = 0.0f;
+                for (int e = 0; e < 8; e++) {
+                    int p = 8 * t + e;
+                    if (T.n_of_bin[T.bin_of_pos[p]] < 0) continue;
+                    cmulc(xr[p], xi[p], pr[p], pi[p], &yr[p], &yi[p]);
+                    float a = fabsf(yr[p]) + fabsf(yi[p]);
+                    acc = acc + a;
+                }
+                part[t] = acc;
+            }
+            float S = reduce256(part), g = 0.0f;
+            if (S > 0.0f && S < INFINITY) { int E; frexpf(S, &E); g = ldexpf(1.0f, SOFT_EXP - E); }
+            int8_t *dst;
+            if (l <= DAB_FIC_SYMS) dst = fic + (l - 1) * DAB_SYM_BITS;
+            else dst = s->ti + (size_t)((cif0 + (l - 4) / DAB_CIF_SYMS) & (s->ti_slots - 1)) * DAB_CIF_BITS + ((l - 4) % DAB_CIF_SYMS) * DAB_SYM_BITS;
+            for (int p = 0; p < NFFT; p++) {
+                int n = T.n_of_bin[T.bin_of_pos[p]];
+                if (n < 0) continue;
+                float a = rintf(yr[p] * g), b = rintf(yi[p] * g);
+                a = a > 127.0f ? 127.0f : (a < -127.0f ? -127.0f : a);
+                b = b > 127.0f ? 127.0f : (b < -127.0f ? -127.0f : b);
+                dst[n] = (int8_t)a; dst[n + DAB_K] = (int8_t)b;
+            }
+        }
+        memcpy(pr, xr, sizeof pr); memcpy(pi, xi, sizeof pi);
+    }
+}
+
+/* ------------------------------------------------------------------ Viterbi
+ * x4: 4 soft values per step (0 where punctured), positive = bit 0.
+ * States: bit 5 newest … bit 0 oldest.  Metric = correlation, maximised.
+ * Tie rule: keep the predecessor whose oldest bit equals the new input bit. */
+void orx_viterbi(const int8_t *x4, int nsteps, uint8_t *bits)
+{
+    int32_t pm[64], nm[64];
+    uint64_t *dec = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nsteps);
+    for (int s = 0; s < 64; s++) pm[s] = PM_INIT;
+    pm[0] = 0;
+    for (int t = 0; t < nsteps; t++) {
+        const int8_t *x = x4 + 4 * t;
+        int32_t bm[16];
+        for (int c = 0; c < 16; c++)
+            bm[c] = ((c & 8) ? -x[0] : x[0]) + ((c & 4) ? -x[1] : x[1]) + ((c & 2) ? -x[2] : x[2]) + ((c & 1) ? -x[3] : x[3]);
+        uint64_t d = 0;
+        for (int ns = 0; ns < 64; ns++) {
+            int u = ns >> 5;
+            int own = ((ns << 1) & 63) | u, oth = own ^ 1;
+            int32_t keep = pm[own] + bm[dab_conv_output(own, u)];
+            int32_t recv = pm[oth] + bm[dab_conv_output(oth, u)];
+            if (recv > keep) { nm[ns] = recv; d |= 1ULL << ns; } else nm[ns] = keep;
+        }
+        memcpy(pm, nm, sizeof pm);
+        dec[t] = d;
+    }
+    int st = 0;                                         /* terminated trellis */
+    for (int t = nsteps - 1; t >= 0; t--) {
+        int u = st >> 5;
+        bits[t] = (uint8_t)u;
+        int own = ((st << 1) & 63) | u;
+        st = ((dec[t] >> st) & 1) ? (own ^ 1) : own;
+    }
+    free(dec);
+}
+
+/* depuncture one codeword through a caller-supplied soft-bit getter */
+typedef int8_t (*soft_fn)(const void *ctx, int i);
+static void decode_cw(const uint32_t *info, int nsteps, int n_in, soft_fn get, const void *ctx, uint8_t *out_bytes)
+{
+    int8_t *x4 = (int8_t *)calloc((size_t)nsteps, 4);
+    uint8_t *bits = (uint8_t *)malloc((size_t)nsteps);
+    for (int t = 0; t < nsteps; t++) {
+        int off = (int)(info[t] >> 4), k = 0;
+        for (int j = 0; j < 4; j++)
+            if (info[t] & (8u >> j)) x4[4 * t + j] = get(ctx, off + k++);
+    }
+    orx_viterbi(x4, nsteps, bits);
+    for (int i = 0; i < n_in / 8; i++) {
+        unsigned v = 0;
+        for (int b = 0; b < 8; b++) v = (v << 1) | (unsigned)(bits[8 * i + b] ^ T.prbs[8 * i + b]);
+        out_bytes[i] = (uint8_t)v;
+    }
+    free(bits); free(x4);
+}
+
+typedef struct { const int8_t *p; } lin_ctx;
+static int8_t get_lin(const void *c, int i) { return ((const lin_ctx *)c)->p[i]; }
+typedef struct { const int8_t *ti; int64_t r; int base; int mask; } ti_ctx;
+static int8_t get_ti(const void *c, int i)
+{
+    const ti_ctx *x = (const ti_ctx *)c;
+    return x->ti[(size_t)((x->r + dab_ti_delay(i)) & x->mask) * DAB_CIF_BITS + x->base + i];
+}
+
+/* stage-level entry for tests: decode a punctured codeword given linear soft bits.
+ * kind 0: FIC codeword; otherwise EEP (option, level, kbps) */
+int orx_decode_linear(int kind, int option, int level, int kbps, const int8_t *soft, uint8_t *out_bytes)
+{
+    tables_init();
+    dab_profile_t p;
+    if (kind == 0) dab_profile_fic(&p); else if (dab_profile_eep(option, level, kbps, &p)) return -1;
+    uint32_t *info = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(p.n_in + 8));
+    int ns = dab_profile_stepinfo(&p, info);
+    lin_ctx c = {soft};
+    decode_cw(info, ns, p.n_in, get_lin, &c, out_bytes);
+    free(info);
+    return p.n_in / 8;
+}
+
+/*
+ * Process n_frames frames.  Output arrays (any may be NULL):
+ *   sync      [n_frames]                    synchronisation records
+ *   fic_soft  [n_frames][9216]              int8
+ *   msc_soft  [n_frames][4][55296]          int8, the CIFs demodulated in this call
+ *   fib       [n_frames][12][32], fib_ok [n_frames][12]
+ *   msc       [n_frames][4][msc_bytes], msc_valid [n_frames][4]
+ * Returns number of frames processed, or <0 when the ring does not hold enough samples.
+ */
+int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8_t *msc_soft,
+                uint8_t *fib, uint8_t *fib_ok, uint8_t *msc, uint8_t *msc_valid)
+{
+    int wide = !s->locked;
+    int64_t need = s->pos + (int64_t)(n_frames + (wide ? 1 : 0)) * DAB_TF + 4096;
+    if (need > s->wr) return -1;
+    if (15 + 4 * n_frames > s->ti_slots) return -3;
+    if (s->wr - s->pos > s->ring_len) return -2;
+    if (wide) {
+        int64_t ns;
+        if (!null_search(s, s->pos, &ns)) {
+            s->pos += (int64_t)n_frames * DAB_TF;
+            if (sync) memset(sync, 0, sizeof(orx_sync_t) * (size_t)n_frames);
+            if (fib_ok) memset(fib_ok, 0, (size_t)n_frames * 12);
+            if (msc_valid) memset(msc_valid, 0, (size_t)n_frames * 4);
+            return 0;
+        }
+        s->pos = ns; s->cif = 0;
+    }
+    int8_t *ficbuf = (int8_t *)malloc(DAB_FIC_BITS);
+    orx_sync_t rec;
+    int nbad = s->bad;
+    for (int f = 0; f < n_frames; f++) {
+        sync_frame(s, s->pos + (int64_t)f * DAB_TF, s->inc, wide, &rec);
+        if (sync) sync[f] = rec;
+        int64_t cif0 = s->cif + 4 * (int64_t)f;
+        demod_frame(s, &rec, cif0, ficbuf);
+        if (fic_soft) memcpy(fic_soft + (size_t)f * DAB_FIC_BITS, ficbuf, DAB_FIC_BITS);
+        if (msc_soft)
+            for (int c = 0; c < 4; c++)
+                memcpy(msc_soft + ((size_t)f * 4 + c) * DAB_CIF_BITS, s->ti + (size_t)((cif0 + c) & (s->ti_slots - 1)) * DAB_CIF_BITS, DAB_CIF_BITS);
+        for (int cw = 0; cw < DAB_FIC_CW; cw++) {
+            uint8_t out[96];
+            lin_ctx lc = {ficbuf + cw * DAB_FIC_CW_BITS};
+            decode_cw(s->fic_stepinfo, DAB_FIC_CW_IN + 6, DAB_FIC_CW_IN, get_lin, &lc, out);
+            for (int j = 0; j < 3; j++) {
+                const uint8_t *fb = out + 32 * j;
+                int ok = dab_crc16(fb, 30) == (uint16_t)((fb[30] << 8) | fb[31]);
+                if (fib) memcpy(fib + ((size_t)f * 12 + 3 * cw + j) * 32, fb, 32);
+                if (fib_ok) fib_ok[(size_t)f * 12 + 3 * cw + j] = (uint8_t)ok;
+            }
+        }
+        for (int c = 0; c < 4; c++) {
+            int64_t r = cif0 + c - 15;                  /* logical frame completed by this CIF */
+            if (msc_valid) msc_valid[(size_t)f * 4 + c] = (uint8_t)(r >= 0);
+            if (!msc) continue;
+            uint8_t *o = msc + ((size_t)f * 4 + c) * (size_t)s->msc_bytes;
+            if (r < 0) { memset(o, 0, (size_t)s->msc_bytes); continue; }
+            for (int k = 0; k < s->n_subch; k++) {
+                subch_t *u = &s->sub[k];
+                ti_ctx tc = {s->ti, r, u->start_cu * DAB_CU_BITS, s->ti_slots - 1};
+                decode_cw(u->stepinfo, u->nsteps, u->prof.n_in, get_ti, &tc, o + u->out_off);
+            }
+        }
+        nbad = (rec.flags & 1) ? 0 : nbad + 1;
+        if (f == n_frames - 1) {
+            s->pos = rec.t_sym0 + BACKOFF - DAB_TG - DAB_TNULL + DAB_TF;
+            s->inc = rec.inc;
+        }
+    }
+    s->cif += 4 * (int64_t)n_frames;
+    s->bad = nbad;
+    /* acquisition succeeds only if its last frame was good; lock drops after 4 bad frames in a row */
+    s->locked = wide ? (nbad == 0) : (nbad < 4);
+    free(ficbuf);
+    return n_frames;
+}

@@ -1,0 +1,302 @@
+/*
+ * oracle/dab_tx.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Seeded synthetic DAB Mode-I transmitter (ETSI EN 300 401 framing, FIC and
+ * MSC coding, time/frequency interleaving, pi/4-DQPSK OFDM) producing the
+ * raw-file sample formats the reference's RawFileInput reads
+ * (reference: src/input/rawfileinput.cpp:640-713 — u8 with value-128, or s16).
+ * It is the source of every input vector in tests/, smoke() and bench.py.
+ * The reference has no transmitter; conventions follow SURVEY.md Appendix B.
+ */
+#include "dab_spec.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    uint64_t seed;
+    int32_t  eid;          /* ensemble id                              */
+    int32_t  n_frames;
+    int32_t  n_subch;      /* sub-channels; cfg in subch[] below       */
+    int32_t  delay;        /* noise-only samples before frame 0        */
+    int32_t  loop;         /* 1: periodic signal, TI history wraps     */
+    int32_t  fmt;          /* 0: u8 IQ, 1: s16 IQ                      */
+    double   snr_db;       /* >= 100: noiseless                        */
+    double   cfo_hz;
+    double   rms;          /* complex RMS of the signal in LSB         */
+    int32_t  subch[64][4]; /* {start_cu, option(0=A,1=B), level, kbps} */
+} dab_tx_cfg_t;
+
+/* ---- deterministic PRNG (splitmix64) ---- */
+static uint64_t sm64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static double urand(uint64_t *s) { return ((sm64(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static void gauss2(uint64_t *s, double *a, double *b)
+{
+    double u = urand(s), v = urand(s), r = sqrt(-2.0 * log(u));
+    *a = r * cos(2.0 * M_PI * v);
+    *b = r * sin(2.0 * M_PI * v);
+}
+
+/* ---- plain double radix-2 inverse FFT (not the receiver's FFT) ---- */
+static void ifft2048(double *re, double *im, const double *tw /* cos,sin of 2*pi*k/2048 */)
+{
+    const int N = DAB_TU;
+    for (int i = 1, j = 0; i < N; i++) {
+        int bit = N >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+    for (int len = 2; len <= N; len <<= 1) {
+        const int st = N / len;
+        for (int i = 0; i < N; i += len)
+            for (int k = 0; k < len / 2; k++) {
+                double wr = tw[2 * k * st], wi = tw[2 * k * st + 1];
+                int a = i + k, b = i + k + len / 2;
+                double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+}
+
+/* ---- FIG / FIB construction (EN 300 401 §5.2, §6, §8) ---- */
+typedef struct { uint8_t b[30]; int len; } fig_t;
+
+static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *figs)
+{
+    int n = 0;
+    /* FIG 0/1 sub-channel organisation, long form, up to 7 entries per FIG */
+    for (int s0 = 0; s0 < c->n_subch; s0 += 7) {
+        fig_t *f = &figs[n++];
+        int cnt = c->n_subch - s0 < 7 ? c->n_subch - s0 : 7;
+        f->b[0] = (uint8_t)(1 + 4 * cnt); f->b[1] = 0x01; f->len = 2;
+        for (int s = s0; s < s0 + cnt; s++) {
+            int addr = c->subch[s][0], size = prof[s].n_cu;
+            f->b[f->len++] = (uint8_t)((s << 2) | (addr >> 8));
+            f->b[f->len++] = (uint8_t)(addr & 0xFF);
+            f->b[f->len++] = (uint8_t)(0x80 | (c->subch[s][1] << 4) | ((c->subch[s][2] - 1) << 2) | (size >> 8));
+            f->b[f->len++] = (uint8_t)(size & 0xFF);
+        }
+    }
+    /* FIG 0/2 basic service organisation: one DAB+ audio service per sub-channel */
+    for (int s0 = 0; s0 < c->n_subch; s0 += 5) {
+        fig_t *f = &figs[n++];
+        int cnt = c->n_subch - s0 < 5 ? c->n_subch - s0 : 5;
+        f->b[0] = (uint8_t)(1 + 5 * cnt); f->b[1] = 0x02; f->len = 2;
+        for (int s = s0; s < s0 + cnt; s++) {
+            int sid = 0x1A01 + s;
+            f->b[f->len++] = (uint8_t)(sid >> 8); f->b[f->len++] = (uint8_t)sid;
+            f->b[f->len++] = 0x01;                           /* one component      */
+            f->b[f->len++] = 0x3F;                           /* TMId 0, ASCTy 63   */
+            f->b[f->len++] = (uint8_t)((s << 2) | 0x02);     /* SubChId, primary   */
+        }
+    }
+    { /* FIG 0/9: LTO +1 h, ECC 0xE2, international table 1 */
+        fig_t *f = &figs[n++];
+        f->b[0] = 0x04; f->b[1] = 0x09; f->b[2] = 0x02; f->b[3] = 0xE2; f->b[4] = 0x01; f->len = 5;
+    }
+    { /* FIG 1/0 ensemble label */
+        fig_t *f = &figs[n++];
+        char lab[17];
+        memcpy(lab, "GRAFT ENS       ", 16);
+        lab[10] = "0123456789ABCDEF"[(c->eid >> 12) & 15]; lab[11] = "0123456789ABCDEF"[(c->eid >> 8) & 15];
+        lab[12] = "0123456789ABCDEF"[(c->eid >> 4) & 15];  lab[13] = "0123456789ABCDEF"[c->eid & 15];
+        f->b[0] = 0x20 | 21; f->b[1] = 0x00; f->b[2] = (uint8_t)(c->eid >> 8); f->b[3] = (uint8_t)c->eid;
+        memcpy(f->b + 4, lab, 16); f->b[20] = 0xFF; f->b[21] = 0x00; f->len = 22;
+    }
+    for (int s = 0; s < c->n_subch; s++) { /* FIG 1/1 programme service labels */
+        fig_t *f = &figs[n++];
+        int sid = 0x1A01 + s;
+        char lab[17];
+        memcpy(lab, "SERVICE 00      ", 16);
+        lab[8] = (char)('0' + s / 10); lab[9] = (char)('0' + s % 10);
+        f->b[0] = 0x20 | 21; f->b[1] = 0x01; f->b[2] = (uint8_t)(sid >> 8); f->b[3] = (uint8_t)sid;
+        memcpy(f->b + 4, lab, 16); f->b[20] = 0xFF; f->b[21] = 0x00; f->len = 22;
+    }
+    return n;
+}
+
+/* one FIB: 30 bytes of FIGs (+0xFF end marker, zero padding) + CRC */
+static void build_fib(uint8_t *fib, int with_fig00, int eid, int cif, const fig_t *figs, int nfig, int *next)
+{
+    int pos = 0;
+    memset(fib, 0, DAB_FIB_BYTES);
+    if (with_fig00) {
+        fib[0] = 0x05; fib[1] = 0x00; fib[2] = (uint8_t)(eid >> 8); fib[3] = (uint8_t)eid;
+        fib[4] = (uint8_t)((cif / 250) % 20); fib[5] = (uint8_t)(cif % 250);
+        pos = 6;
+    }
+    for (int tries = 0; tries < nfig; tries++) {
+        const fig_t *f = &figs[*next % nfig];
+        if (pos + f->len > 30) break;
+        memcpy(fib + pos, f->b, (size_t)f->len);
+        pos += f->len;
+        (*next)++;
+    }
+    if (pos < 30) fib[pos] = 0xFF;
+    uint16_t crc = dab_crc16(fib, 30);
+    fib[30] = (uint8_t)(crc >> 8); fib[31] = (uint8_t)crc;
+}
+
+static void bytes_to_bits(const uint8_t *by, int nbytes, uint8_t *bits)
+{
+    for (int i = 0; i < nbytes; i++)
+        for (int b = 0; b < 8; b++) bits[8 * i + b] = (by[i] >> (7 - b)) & 1;
+}
+
+/* energy dispersal + mother code + puncturing of one codeword */
+static void encode_cw(const dab_profile_t *p, const uint8_t *info_bytes, const uint8_t *prbs, uint8_t *coded,
+                      uint8_t *tmp_bits, uint8_t *tmp_mother)
+{
+    bytes_to_bits(info_bytes, p->n_in / 8, tmp_bits);
+    for (int i = 0; i < p->n_in; i++) tmp_bits[i] ^= prbs[i];
+    dab_conv_encode(tmp_bits, p->n_in, tmp_mother);
+    dab_puncture(p, tmp_mother, coded);
+}
+
+/* sizes the caller must provide */
+int dab_tx_msc_bytes_per_cif(const dab_tx_cfg_t *c)
+{
+    int tot = 0;
+    dab_profile_t p;
+    for (int s = 0; s < c->n_subch; s++) {
+        if (dab_profile_eep(c->subch[s][1], c->subch[s][2], c->subch[s][3], &p)) return -1;
+        tot += p.n_in / 8;
+    }
+    return tot;
+}
+
+/*
+ * Generate n_frames transmission frames.
+ *   iq        : (delay + n_frames*196608) complex samples, interleaved I,Q (u8 or s16)
+ *   fib_out   : n_frames*12*32 bytes, the transmitted FIBs (incl. CRC)
+ *   msc_out   : n_frames*4 logical frames x msc_bytes_per_cif payload bytes
+ *               (sub-channels concatenated in cfg order), before dispersal
+ * Returns 0 on success.
+ */
+int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *msc_out)
+{
+    const int NF = c->n_frames, NC = NF * DAB_CIFS;
+    dab_profile_t prof[64], ficp;
+    if (c->n_subch < 0 || c->n_subch > 64 || NF < 1) return -1;
+    int msc_bytes = 0, off_bytes[64];
+    for (int s = 0; s < c->n_subch; s++) {
+        if (dab_profile_eep(c->subch[s][1], c->subch[s][2], c->subch[s][3], &prof[s])) return -2;
+        if (c->subch[s][0] < 0 || c->subch[s][0] + prof[s].n_cu > DAB_NCU) return -3;
+        off_bytes[s] = msc_bytes;
+        msc_bytes += prof[s].n_in / 8;
+    }
+    if (c->loop && (NC % DAB_TI_DEPTH)) return -4;
+    dab_profile_fic(&ficp);
+
+    uint64_t rng = c->seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+    uint64_t nrng = c->seed * 0xD1342543DE82EF95ULL + 0x7654321ULL;
+    uint8_t *prbs = (uint8_t *)malloc(DAB_CIF_BITS);
+    uint8_t *tmp_bits = (uint8_t *)malloc(DAB_CIF_BITS + 64);
+    uint8_t *tmp_mother = (uint8_t *)malloc(4 * (DAB_CIF_BITS + 64));
+    uint8_t *coded = (uint8_t *)calloc((size_t)NC, DAB_CIF_BITS);      /* logical frames, pre-interleaver */
+    uint8_t *ficbits = (uint8_t *)malloc((size_t)NF * DAB_FIC_BITS);
+    fig_t *figs = (fig_t *)calloc(256, sizeof(fig_t));
+    double *re = (double *)malloc(sizeof(double) * DAB_TU), *im = (double *)malloc(sizeof(double) * DAB_TU);
+    int16_t kofn[DAB_K];
+    int8_t prsq[DAB_TU];
+    uint8_t ph8[DAB_TU];
+    uint8_t symbits[DAB_SYM_BITS];
+    double *tw = (double *)malloc(sizeof(double) * 2 * DAB_TU);
+    for (int k = 0; k < DAB_TU; k++) { tw[2 * k] = cos(2.0 * M_PI * k / DAB_TU); tw[2 * k + 1] = sin(2.0 * M_PI * k / DAB_TU); }
+    dab_prbs(prbs, DAB_CIF_BITS);
+    dab_freq_interleaver(kofn);
+    dab_prs_quadrants(prsq);
+    int nfig = build_figs(c, prof, figs), nextfig = 0;
+
+    /* ---- FIC: 4 codewords of 3 FIBs per frame ---- */
+    for (int f = 0; f < NF; f++)
+        for (int cw = 0; cw < DAB_FIC_CW; cw++) {
+            uint8_t *fibs = fib_out + ((size_t)f * 12 + 3 * cw) * DAB_FIB_BYTES;
+            for (int j = 0; j < 3; j++)
+                build_fib(fibs + j * DAB_FIB_BYTES, j == 0, c->eid, f * 4 + cw, figs, nfig, &nextfig);
+            encode_cw(&ficp, fibs, prbs, ficbits + (size_t)f * DAB_FIC_BITS + cw * DAB_FIC_CW_BITS, tmp_bits, tmp_mother);
+        }
+    /* ---- MSC logical frames ---- */
+    for (int r = 0; r < NC; r++)
+        for (int s = 0; s < c->n_subch; s++) {
+            uint8_t *pay = msc_out + (size_t)r * msc_bytes + off_bytes[s];
+            int nb = prof[s].n_in / 8;
+            for (int i = 0; i < nb; i += 8) {
+                uint64_t x = sm64(&rng);
+                for (int j = 0; j < 8 && i + j < nb; j++) pay[i + j] = (uint8_t)(x >> (8 * j));
+            }
+            encode_cw(&prof[s], pay, prbs, coded + (size_t)r * DAB_CIF_BITS + c->subch[s][0] * DAB_CU_BITS, tmp_bits, tmp_mother);
+        }
+
+    /* ---- modulation ---- */
+    const double amp = c->rms * DAB_TU / sqrt((double)DAB_K);
+    const double nsig = (c->snr_db >= 100.0) ? 0.0 : c->rms * pow(10.0, -c->snr_db / 20.0) / sqrt(2.0);
+    const double lim_lo = c->fmt ? -32768.0 : 0.0, lim_hi = c->fmt ? 32767.0 : 255.0, bias = c->fmt ? 0.0 : 128.0;
+    const size_t total = (size_t)c->delay + (size_t)NF * DAB_TF;
+    double *frame = (double *)malloc(sizeof(double) * 2 * DAB_TF);
+    size_t nabs = 0;
+    for (int f = -1; f < NF; f++) {
+        size_t len = (f < 0) ? (size_t)c->delay : DAB_TF;
+        if (len == 0) continue;
+        memset(frame, 0, sizeof(double) * 2 * len);
+        if (f >= 0) {
+            for (int b = 0; b < DAB_TU; b++) ph8[b] = (uint8_t)(prsq[b] < 0 ? 0 : 2 * prsq[b]);
+            for (int l = 0; l < DAB_NSYM; l++) {
+                if (l > 0) {
+                    if (l <= DAB_FIC_SYMS) memcpy(symbits, ficbits + (size_t)f * DAB_FIC_BITS + (l - 1) * DAB_SYM_BITS, DAB_SYM_BITS);
+                    else {
+                        int t = f * DAB_CIFS + (l - 4) / DAB_CIF_SYMS;           /* transmitted CIF index */
+                        int base = ((l - 4) % DAB_CIF_SYMS) * DAB_SYM_BITS;
+                        for (int i = 0; i < DAB_SYM_BITS; i++) {
+                            int r = t - dab_ti_delay(base + i);
+                            if (r < 0) r = c->loop ? r + NC : -1;
+                            symbits[i] = (r < 0) ? 0 : coded[(size_t)r * DAB_CIF_BITS + base + i];
+                        }
+                    }
+                    for (int n = 0; n < DAB_K; n++) {
+                        int b = kofn[n] & 2047;
+                        int y = symbits[n] ? (symbits[n + DAB_K] ? 5 : 3) : (symbits[n + DAB_K] ? 7 : 1);
+                        ph8[b] = (uint8_t)((ph8[b] + y) & 7);
+                    }
+                }
+                for (int b = 0; b < DAB_TU; b++) {
+                    if (prsq[b] < 0) { re[b] = im[b] = 0.0; continue; }
+                    static const double c8[8] = {1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2, 0, M_SQRT1_2};
+                    re[b] = c8[ph8[b]]; im[b] = c8[(ph8[b] + 6) & 7];
+                }
+                ifft2048(re, im, tw);
+                double *o = frame + 2 * ((size_t)DAB_TNULL + (size_t)l * DAB_TS);
+                for (int n = 0; n < DAB_TS; n++) {
+                    int src = (n + DAB_TU - DAB_TG) & (DAB_TU - 1);
+                    o[2 * n] = re[src] * amp / DAB_TU; o[2 * n + 1] = im[src] * amp / DAB_TU;
+                }
+            }
+        }
+        for (size_t n = 0; n < len; n++, nabs++) {
+            double xr = frame[2 * n], xi = frame[2 * n + 1];
+            if (c->cfo_hz != 0.0) {
+                double a = 2.0 * M_PI * fmod(c->cfo_hz * (double)nabs / DAB_FS, 1.0);
+                double cr = cos(a), ci = sin(a), t = xr * cr - xi * ci;
+                xi = xr * ci + xi * cr; xr = t;
+            }
+            if (nsig > 0.0) { double g1, g2; gauss2(&nrng, &g1, &g2); xr += nsig * g1; xi += nsig * g2; }
+            double qr = floor(xr + 0.5) + bias, qi = floor(xi + 0.5) + bias;
+            qr = qr < lim_lo ? lim_lo : (qr > lim_hi ? lim_hi : qr);
+            qi = qi < lim_lo ? lim_lo : (qi > lim_hi ? lim_hi : qi);
+            if (c->fmt) { ((int16_t *)iq)[2 * nabs] = (int16_t)qr; ((int16_t *)iq)[2 * nabs + 1] = (int16_t)qi; }
+            else { ((uint8_t *)iq)[2 * nabs] = (uint8_t)qr; ((uint8_t *)iq)[2 * nabs + 1] = (uint8_t)qi; }
+        }
+    }
+    (void)total;
+    free(tw); free(frame); free(re); free(im); free(figs); free(ficbits); free(coded);
+    free(tmp_mother); free(tmp_bits); free(prbs);
+    return 0;
+}
