@@ -1,0 +1,474 @@
+// dabsdr_shim.cpp — the reference's 24-function dabsdr C API over a one-stream
+// dabx context (include/dabsdr_amd.h cites the declaration each function replaces).
+//
+// Threading mirrors the reference: dabsdr() spawns one
+// worker thread named "dabsdr"; every callback fires on that thread; requests
+// are queued from any thread and answered by notifications.  The worker pulls
+// whole transmission frames through the registered input callback
+// (reference contract: src/input/inputdevice.cpp:70-108 — blocking, fills the
+// buffer completely, zeros when flushed), rounds them to s16 and pushes them into
+// the GPU ring, so the reference's raw-file input drops in unchanged.
+#include "../../include/dabsdr_amd.h"
+#include "../../include/dabx.h"
+#include "fig_db.hpp"
+
+#include <pthread.h>
+
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+enum class Req { Tune, GetEnsemble, GetServiceList, GetServiceComponents, GetUserAppList, GetAnnouncementSupport,
+                 ServiceSelection, ServiceStop, XPadAppStart, SetPeriodicNotify, SetTII, SignalSpectrum, Exit };
+
+struct Request {
+    Req kind;
+    uint32_t a = 0;      // frequency / SId
+    int32_t b = 0;       // SCIdS / period / enable
+    int32_t c = 0;       // decoder id / cfg
+};
+
+constexpr int kPullChunk = 16384;        // complex samples per input-callback call (uint16_t length)
+
+}  // namespace
+
+struct dabsdr_s {
+    dabx_ctx *ctx = nullptr;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Request> queue;
+    std::atomic<bool> exit_req{false};
+    bool started = false;
+
+    dabsdrInputFunc_t input = nullptr, dummy = nullptr;
+    dabsdrAudioCBFunc_t audio_cb = nullptr; void *audio_ctx = nullptr;
+    dabsdrDynamicLabelCBFunc_t dl_cb = nullptr; void *dl_ctx = nullptr;
+    dabsdrDataGroupCBFunc_t dg_cb = nullptr; void *dg_ctx = nullptr;
+    dabsdrSpectrumCBFunc_t spec_cb = nullptr; void *spec_ctx = nullptr;
+    dabsdrNotificationCBFunc_t ntf_cb = nullptr; void *ntf_ctx = nullptr;
+
+    // worker-thread state
+    uint32_t frequency = 0;
+    int gain_shift = 0;                  // float -> s16 scaling: x * 2^gain_shift
+    bool gain_set = false;
+    dabsdrSyncLevel_t sync_level = DABSDR_SYNC_LEVEL_NO_SYNC;
+    int period_log2 = -1;                // periodic notification every 2^n frames, <0 = off
+    int period_frames = 0;
+    uint32_t fib_err_acc = 0;
+    figdb::Database db;
+    uint32_t sel_sid = 0; int sel_scids = -1; bool sel_active = false;
+    std::vector<figdb::Service> list_snapshot;       // for the list getters (valid during a callback)
+    std::vector<figdb::Component> comp_snapshot;
+    uint32_t comp_sid = 0;
+    std::vector<float> fbuf;
+    std::vector<int16_t> sbuf;
+};
+
+namespace {
+
+void notify(dabsdr_s *h, dabsdrNotificationId_t nid, dabsdrNotificationStatus_t st, const void *data, uint16_t len)
+{
+    if (!h->ntf_cb) return;
+    dabsdrNotificationCBData_t d;
+    d.nid = nid; d.status = st; d.len = len; d.pData = data;
+    h->ntf_cb(&d, h->ntf_ctx);
+}
+
+void fill_label(dabsdrLabel_t &l, const std::string &s, uint16_t flag)
+{
+    std::memset(&l, 0, sizeof l);
+    std::memcpy(l.str, s.data(), s.size() < 16 ? s.size() : 16);
+    l.charField = flag;
+    l.charset = 0;
+}
+
+int protection_enum(const figdb::SubChannel &sc)
+{
+    // numbering of the reference's DabProtectionLevel (src/dabtables.h:35-55):
+    // UEP 1..5 = 1..5, EEP 1-A..4-A = 6..9, EEP 1-B..4-B = 10..13
+    if (!sc.long_form) return 0;
+    return (sc.option == 0 ? 5 : 9) + sc.level;
+}
+
+int get_service_item(dabsdrHandle_t h, uint8_t idx, dabsdrServiceListItem_t *out)
+{
+    if (!h || !out || idx >= h->list_snapshot.size()) return -1;
+    const figdb::Service &s = h->list_snapshot[idx];
+    std::memset(out, 0, sizeof *out);
+    out->sid = s.sid;
+    fill_label(out->label, s.label, s.label_flag);
+    out->pty.s = out->pty.d = s.pty < 0 ? 255 : static_cast<uint8_t>(s.pty);
+    out->CAId = static_cast<uint8_t>(s.caid);
+    return 0;
+}
+
+int get_component_item(dabsdrHandle_t h, uint8_t idx, dabsdrServiceCompListItem_t *out)
+{
+    if (!h || !out || idx >= h->comp_snapshot.size()) return -1;
+    const figdb::Component &c = h->comp_snapshot[idx];
+    std::memset(out, 0, sizeof *out);
+    out->SCIdS = static_cast<uint8_t>(c.scids);
+    out->SubChAddr = -1;
+    out->ps = c.primary ? 1 : 0;
+    out->lang = 0;
+    out->CAflag = c.ca;
+    out->TMId = static_cast<uint8_t>(c.tmid);
+    fill_label(out->label, c.label, c.label_flag);
+    auto it = h->db.subch.find(c.subch);
+    if (c.tmid != 3 && it != h->db.subch.end()) {
+        const figdb::SubChannel &sc = it->second;
+        out->SubChId = static_cast<uint8_t>(sc.id);
+        out->SubChAddr = static_cast<int16_t>(sc.start);
+        out->SubChSize = static_cast<uint16_t>(sc.size);
+        out->protectionLevel = static_cast<uint8_t>(protection_enum(sc));
+        if (c.tmid == 0) { out->streamAudio.ASCTy = static_cast<uint8_t>(c.ascty_dscty); out->streamAudio.bitRate = static_cast<uint16_t>(sc.kbps); }
+        else { out->streamData.DSCTy = static_cast<uint8_t>(c.ascty_dscty); out->streamData.bitRate = static_cast<uint16_t>(sc.kbps); }
+    } else if (c.tmid == 3) {
+        out->packetData.SCId = static_cast<uint16_t>(c.scid);
+        out->packetData.packetAddress = -1;
+    }
+    return 0;
+}
+
+void reset_receiver(dabsdr_s *h, dabsdrNtfResetFlags_t flag)
+{
+    h->db.clear();
+    h->sync_level = DABSDR_SYNC_LEVEL_NO_SYNC;
+    h->fib_err_acc = 0; h->period_frames = 0;
+    h->sel_active = false;
+    notify(h, DABSDR_NID_RESET, DABSDR_NSTAT_SUCCESS, &flag, 0);
+}
+
+void handle_request(dabsdr_s *h, const Request &r)
+{
+    switch (r.kind) {
+    case Req::Tune: {
+        if (r.a == 0) {
+            reset_receiver(h, DABSDR_RESET_INIT);
+            h->frequency = 0;
+            uint32_t f = 0;
+            notify(h, DABSDR_NID_TUNE, DABSDR_NSTAT_SUCCESS, &f, 0);
+        } else {
+            h->frequency = r.a;
+            h->gain_set = false;
+            // a fresh context state: drop everything buffered so far
+            if (h->ctx) {
+                dabx_config_t cfg = {1, DABX_FMT_S16, 8LL * DABX_FRAME_SAMPLES, 1, 0};
+                dabx_destroy(h->ctx);
+                h->ctx = nullptr;
+                if (dabx_create(&cfg, &h->ctx) != DABX_OK) h->ctx = nullptr;
+            }
+            uint32_t f = r.a;
+            notify(h, DABSDR_NID_TUNE, h->ctx ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_GENERIC_ERROR, &f, 0);
+            reset_receiver(h, DABSDR_RESET_INIT);
+        }
+        break;
+    }
+    case Req::GetEnsemble: {
+        dabsdrNtfEnsemble_t e;
+        std::memset(&e, 0, sizeof e);
+        e.frequency = h->frequency;
+        const bool ok = h->db.ens.eid >= 0;
+        e.ueid = ok ? (static_cast<uint32_t>(h->db.ens.ecc) << 16) | static_cast<uint32_t>(h->db.ens.eid) : 0;
+        e.LTO = static_cast<int8_t>(h->db.ens.lto);
+        e.intTable = static_cast<uint8_t>(h->db.ens.int_table);
+        e.alarm = static_cast<uint8_t>(h->db.ens.alarm);
+        fill_label(e.label, h->db.ens.label, h->db.ens.label_flag);
+        notify(h, DABSDR_NID_ENSEMBLE_INFO, ok ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_GENERIC_ERROR, &e, sizeof e);
+        break;
+    }
+    case Req::GetServiceList: {
+        h->list_snapshot.clear();
+        for (const auto &kv : h->db.services)
+            if (!kv.second.comp.empty()) h->list_snapshot.push_back(kv.second);
+        dabsdrNtfServiceList_t l;
+        l.numServices = static_cast<uint8_t>(h->list_snapshot.size() > 255 ? 255 : h->list_snapshot.size());
+        l.getServiceListItem = get_service_item;
+        notify(h, DABSDR_NID_SERVICE_LIST, DABSDR_NSTAT_SUCCESS, &l, sizeof l);
+        break;
+    }
+    case Req::GetServiceComponents: {
+        dabsdrNtfServiceComponentList_t l;
+        std::memset(&l, 0, sizeof l);
+        l.SId = r.a;
+        l.getServiceComponentListItem = get_component_item;
+        const figdb::Service *s = h->db.find_service(r.a);
+        h->comp_snapshot.clear();
+        if (s) h->comp_snapshot = s->comp;
+        h->comp_sid = r.a;
+        l.numServiceComponents = static_cast<uint8_t>(h->comp_snapshot.size());
+        notify(h, DABSDR_NID_SERVICE_COMPONENT_LIST, s ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_SERVICE_NOT_FOUND, &l, sizeof l);
+        break;
+    }
+    case Req::GetUserAppList: {
+        dabsdrNtfUserAppList_t l;
+        std::memset(&l, 0, sizeof l);
+        l.SId = r.a; l.SCIdS = static_cast<uint8_t>(r.b);
+        l.getUserAppListItem = [](dabsdrHandle_t, uint8_t, dabsdrUserAppListItem_t *) { return -1; };
+        notify(h, DABSDR_NID_USER_APP_LIST, DABSDR_NSTAT_SUCCESS, &l, sizeof l);
+        break;
+    }
+    case Req::GetAnnouncementSupport: {
+        dabsdrNtfAnnouncementSupport_t a;
+        std::memset(&a, 0, sizeof a);
+        a.SId = r.a;
+        notify(h, DABSDR_NID_ANNOUNCEMENT_SUPPORT, DABSDR_NSTAT_SUCCESS, &a, sizeof a);
+        break;
+    }
+    case Req::ServiceSelection: {
+        dabsdrNtfServiceSelection_t s = {r.a, static_cast<uint8_t>(r.b), static_cast<dabsdrDecoderId_t>(r.c)};
+        dabsdrNotificationStatus_t st = DABSDR_NSTAT_SERVICE_NOT_FOUND;
+        const figdb::Service *sv = h->db.find_service(r.a);
+        if (sv && h->ctx) {
+            for (const auto &c : sv->comp) {
+                if (c.scids != r.b) continue;
+                auto it = h->db.subch.find(c.subch);
+                if (c.tmid == 3 || it == h->db.subch.end()) { st = DABSDR_NSTAT_SERVICE_NOT_READY; break; }
+                if (!it->second.long_form) { st = DABSDR_NSTAT_SERVICE_NOT_SUPPORTED; break; }   // UEP: next round
+                dabx_subch_t sc = {it->second.start, it->second.option, it->second.level, it->second.kbps};
+                st = dabx_set_subchannels(h->ctx, 0, 1, &sc) >= 0 ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_SERVICE_NOT_SUPPORTED;
+                if (st == DABSDR_NSTAT_SUCCESS) { h->sel_sid = r.a; h->sel_scids = r.b; h->sel_active = true; }
+                break;
+            }
+        }
+        notify(h, DABSDR_NID_SERVICE_SELECTION, st, &s, sizeof s);
+        break;
+    }
+    case Req::ServiceStop: {
+        dabsdrNtfServiceStop_t s = {r.a, static_cast<uint8_t>(r.b), static_cast<dabsdrDecoderId_t>(r.c)};
+        if (h->ctx) dabx_set_subchannels(h->ctx, 0, 0, nullptr);
+        h->sel_active = false;
+        notify(h, DABSDR_NID_SERVICE_STOP, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
+        break;
+    }
+    case Req::XPadAppStart: {
+        dabsdrNtfXpadAppStartStop_t x = {static_cast<uint8_t>(r.a), static_cast<int8_t>(r.b)};
+        notify(h, DABSDR_NID_XPAD_APP_START_STOP, DABSDR_NSTAT_SUCCESS, &x, sizeof x);
+        break;
+    }
+    case Req::SetPeriodicNotify:
+        h->period_log2 = r.b;
+        h->period_frames = 0; h->fib_err_acc = 0;
+        notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, nullptr, 0);      // acknowledgement, no payload
+        break;
+    case Req::SetTII:
+    case Req::SignalSpectrum:
+    case Req::Exit:
+        break;
+    }
+}
+
+// float IQ from the host -> s16 IQ.  Raw-file input arrives as exact integers
+// (reference: src/input/rawfileinput.cpp:657,692), for which the shift is 0 and
+// the conversion is lossless; other amplitudes get a power-of-two gain.
+void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
+{
+    if (!h->gain_set) {
+        float mx = 0.0f;
+        for (int i = 0; i < n_values; ++i) mx = std::fmax(mx, std::fabs(in[i]));
+        int sh = 0;
+        if (mx > 0.0f) {
+            while (mx * std::ldexp(1.0f, sh) > 16384.0f) --sh;
+            while (mx * std::ldexp(1.0f, sh) < 64.0f && sh < 24) ++sh;
+        }
+        h->gain_shift = sh;
+        h->gain_set = mx > 0.0f;
+    }
+    const float g = std::ldexp(1.0f, h->gain_shift);
+    for (int i = 0; i < n_values; ++i) {
+        float v = std::nearbyint(in[i] * g);
+        out[i] = static_cast<int16_t>(v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v));
+    }
+}
+
+void after_step(dabsdr_s *h)
+{
+    uint8_t fib[12 * 32], ok[12];
+    dabx_stream_state_t st;
+    dabx_sync_rec_t rec;
+    if (dabx_get_fib(h->ctx, 0, fib, ok) || dabx_get_state(h->ctx, 0, &st) || dabx_get_sync(h->ctx, 0, &rec)) return;
+    int good = 0;
+    for (int i = 0; i < 12; ++i)
+        if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
+    const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
+    // SNR estimate from the impulse response: peak power against the rest
+    int16_t snr10 = 0;
+    if (rec.total > 0.0f && rec.peak > 0.0f) {
+        const float rest = rec.total - rec.peak / 1.0f;
+        const float ratio = rest > 0.0f ? rec.peak / rest : 1e6f;
+        snr10 = static_cast<int16_t>(std::fmin(400.0f, std::fmax(-100.0f, 100.0f * std::log10(ratio / 1536.0f * 1536.0f) / 10.0f)));
+    }
+    if (lvl != h->sync_level) {
+        h->sync_level = lvl;
+        dabsdrNtfSyncStatus_t s = {lvl, snr10};
+        notify(h, DABSDR_NID_SYNC_STATUS, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
+    }
+    h->fib_err_acc += static_cast<uint32_t>(12 - good);
+    if (h->period_log2 >= 0 && ++h->period_frames >= (1 << h->period_log2)) {
+        dabsdrNtfPeriodic_t p;
+        std::memset(&p, 0, sizeof p);
+        p.syncLevel = lvl;
+        p.snr10 = snr10;
+        // inc is 2^-32 turn per sample at 2.048 MHz; the host wants Hz * 10
+        p.freqOffset = static_cast<int32_t>(std::llround(static_cast<double>(st.inc) * 2048000.0 * 10.0 / 4294967296.0));
+        if (h->db.ens.utc_valid) {
+            p.dateHoursMinutes = (h->db.ens.mjd << 11) | (static_cast<uint32_t>(h->db.ens.hours) << 6) | static_cast<uint32_t>(h->db.ens.minutes);
+            p.secMsec = static_cast<uint16_t>((h->db.ens.seconds << 10) | h->db.ens.ms);
+        }
+        p.fibErrorCntr = static_cast<uint16_t>(h->fib_err_acc);
+        notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, &p, sizeof p);
+        h->period_frames = 0; h->fib_err_acc = 0;
+    }
+}
+
+void worker_main(dabsdr_s *h)
+{
+    pthread_setname_np(pthread_self(), "dabsdr");
+    h->fbuf.resize(2 * kPullChunk);
+    h->sbuf.resize(2 * kPullChunk);
+    while (!h->exit_req.load()) {
+        std::deque<Request> todo;
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            if (h->frequency == 0 && h->queue.empty()) h->cv.wait(lk, [&] { return !h->queue.empty() || h->exit_req.load(); });
+            todo.swap(h->queue);
+        }
+        for (const Request &r : todo) {
+            if (r.kind == Req::Exit) return;
+            handle_request(h, r);
+        }
+        if (h->frequency == 0 || !h->ctx || !h->input) continue;
+        // one transmission frame of input, then decode whatever is complete
+        for (int got = 0; got < DABX_FRAME_SAMPLES && !h->exit_req.load(); got += kPullChunk) {
+            h->input(h->fbuf.data(), static_cast<uint16_t>(kPullChunk));
+            convert(h, h->fbuf.data(), h->sbuf.data(), 2 * kPullChunk);
+            if (dabx_push(h->ctx, 0, h->sbuf.data(), kPullChunk, 0) != DABX_OK) break;
+        }
+        while (!h->exit_req.load() && dabx_frames_available(h->ctx) >= 1) {
+            if (dabx_process(h->ctx, 1) != DABX_OK) break;
+            after_step(h);
+        }
+    }
+}
+
+void post(dabsdrHandle_t h, Request r)
+{
+    if (!h) return;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->queue.push_back(r);
+    }
+    h->cv.notify_all();
+}
+
+}  // namespace
+
+extern "C" {
+
+uint8_t dabsdrInit(dabsdrHandle_t *handle)
+{
+    if (!handle) return EXIT_FAILURE;
+    dabsdr_s *h = new (std::nothrow) dabsdr_s;
+    if (!h) return EXIT_FAILURE;
+    dabx_config_t cfg = {1, DABX_FMT_S16, 8LL * DABX_FRAME_SAMPLES, 1, 0};
+    if (dabx_create(&cfg, &h->ctx) != DABX_OK) {     // no GPU: fail loudly, there is no CPU path
+        delete h;
+        *handle = nullptr;
+        return EXIT_FAILURE;
+    }
+    *handle = h;
+    return EXIT_SUCCESS;
+}
+
+void dabsdrGetVersion(dabsdrVersion_t *v)
+{
+    if (!v) return;
+    v->major = 4; v->minor = 0; v->patch = 1;       // API level of the reference library this replaces
+    v->flags = 0x80;                                // bit 7: GPU implementation
+}
+
+void dabsdr(dabsdrHandle_t h)
+{
+    if (!h || h->started) return;
+    h->started = true;
+    h->worker = std::thread(worker_main, h);
+}
+
+void dabsdrDeinit(dabsdrHandle_t *handle)
+{
+    if (!handle || !*handle) return;
+    dabsdr_s *h = *handle;
+    h->exit_req.store(true);
+    h->cv.notify_all();
+    if (h->worker.joinable()) h->worker.join();
+    if (h->ctx) dabx_destroy(h->ctx);
+    delete h;
+    *handle = nullptr;
+}
+
+void dabsdrRegisterInputFcn(dabsdrHandle_t h, dabsdrInputFunc_t f) { if (h) h->input = f; }
+void dabsdrRegisterDummyInputFcn(dabsdrHandle_t h, dabsdrInputFunc_t f) { if (h) h->dummy = f; }   // never needed: whole frames are consumed
+void dabsdrRegisterAudioCb(dabsdrHandle_t h, dabsdrAudioCBFunc_t f, void *c) { if (h) { h->audio_cb = f; h->audio_ctx = c; } }
+void dabsdrRegisterDynamicLabelCb(dabsdrHandle_t h, dabsdrDynamicLabelCBFunc_t f, void *c) { if (h) { h->dl_cb = f; h->dl_ctx = c; } }
+void dabsdrRegisterDataGroupCb(dabsdrHandle_t h, dabsdrDataGroupCBFunc_t f, void *c) { if (h) { h->dg_cb = f; h->dg_ctx = c; } }
+void dabsdrRegisterSignalSpectrumCb(dabsdrHandle_t h, dabsdrSpectrumCBFunc_t f, void *c) { if (h) { h->spec_cb = f; h->spec_ctx = c; } }
+void dabsdrRegisterNotificationCb(dabsdrHandle_t h, dabsdrNotificationCBFunc_t f, void *c) { if (h) { h->ntf_cb = f; h->ntf_ctx = c; } }
+
+void dabsdrRequest_Tune(dabsdrHandle_t h, uint32_t f) { post(h, {Req::Tune, f, 0, 0}); }
+void dabsdrRequest_GetEnsemble(dabsdrHandle_t h) { post(h, {Req::GetEnsemble, 0, 0, 0}); }
+void dabsdrRequest_GetServiceList(dabsdrHandle_t h) { post(h, {Req::GetServiceList, 0, 0, 0}); }
+void dabsdrRequest_GetServiceComponents(dabsdrHandle_t h, uint32_t sid) { post(h, {Req::GetServiceComponents, sid, 0, 0}); }
+void dabsdrRequest_GetUserAppList(dabsdrHandle_t h, uint32_t sid, uint8_t scids) { post(h, {Req::GetUserAppList, sid, scids, 0}); }
+void dabsdrRequest_GetAnnouncementSupport(dabsdrHandle_t h, uint32_t sid) { post(h, {Req::GetAnnouncementSupport, sid, 0, 0}); }
+void dabsdrRequest_ServiceSelection(dabsdrHandle_t h, uint32_t sid, uint8_t scids, dabsdrDecoderId_t id) { post(h, {Req::ServiceSelection, sid, scids, id}); }
+void dabsdrRequest_ServiceStop(dabsdrHandle_t h, uint32_t sid, uint8_t scids, dabsdrDecoderId_t id) { post(h, {Req::ServiceStop, sid, scids, id}); }
+void dabsdrRequest_XPadAppStart(dabsdrHandle_t h, uint8_t app, int8_t start, dabsdrDecoderId_t id) { post(h, {Req::XPadAppStart, app, start, id}); }
+void dabsdrRequest_SetPeriodicNotify(dabsdrHandle_t h, uint8_t period, uint32_t cfg) { post(h, {Req::SetPeriodicNotify, 0, period, static_cast<int32_t>(cfg)}); }
+void dabsdrRequest_SetTII(dabsdrHandle_t h, uint8_t ena, dabsdrTiiMode_t mode) { post(h, {Req::SetTII, ena, mode, 0}); }
+void dabsdrRequest_SignalSpectrum(dabsdrHandle_t h, uint8_t ena) { post(h, {Req::SignalSpectrum, ena, 0, 0}); }
+void dabsdrRequest_Exit(dabsdrHandle_t h)
+{
+    if (!h) return;
+    h->exit_req.store(true);
+    post(h, {Req::Exit, 0, 0, 0});
+}
+
+// test hook (CPU only): parse FIBs and print the ensemble as text, see tests/test_figdb.py
+DABSDR_API int dabsdr_amd_fig_dump(const uint8_t *fibs, int n_fibs, char *out, int cap)
+{
+    figdb::Database db;
+    for (int i = 0; i < n_fibs; ++i) db.parse_fib(fibs + 32 * i);
+    std::string s;
+    char line[160];
+    std::snprintf(line, sizeof line, "ensemble eid=%04X ecc=%02X lto=%d label='%s' cif=%d\n", db.ens.eid & 0xFFFF, db.ens.ecc,
+                  db.ens.lto, db.ens.label.c_str(), db.ens.cif_count);
+    s += line;
+    for (const auto &kv : db.subch) {
+        std::snprintf(line, sizeof line, "subch id=%d start=%d size=%d opt=%d level=%d kbps=%d\n", kv.second.id, kv.second.start,
+                      kv.second.size, kv.second.option, kv.second.level, kv.second.kbps);
+        s += line;
+    }
+    for (const auto &kv : db.services) {
+        std::snprintf(line, sizeof line, "service sid=%04X label='%s' ncomp=%zu", kv.second.sid, kv.second.label.c_str(), kv.second.comp.size());
+        s += line;
+        for (const auto &c : kv.second.comp) {
+            std::snprintf(line, sizeof line, " [tmid=%d ty=%d subch=%d ps=%d]", c.tmid, c.ascty_dscty, c.subch, c.primary ? 1 : 0);
+            s += line;
+        }
+        s += "\n";
+    }
+    if (static_cast<int>(s.size()) + 1 > cap) return -1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return static_cast<int>(s.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,561 @@
+// dabx_api.hip — host side of the batch C ABI (include/dabx.h).
+//
+// Owns the HBM buffers (layout in dabx_dev.h), the per-stream bookkeeping that
+// the reference keeps in its global sample FIFO (reference:
+// src/input/inputdevice.cpp:30-131) and the launch sequence of one decode step.
+#include "dabx_kernels.hip"
+#include "dabx_spec.hpp"
+#include "../../include/dabx.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int kLdsMaxSteps = 1984;   // 4 waves x 62 half-blocks x 64 decision words x 4 B = 62 KiB of LDS per workgroup
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            std::fprintf(stderr, "dabx: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? DABX_E_NOMEM : DABX_E_NODEV;                            \
+        }                                                                                              \
+    } while (0)
+
+template <class T>
+int dev_upload(T *&dst, const std::vector<T> &src)
+{
+    if (dst) (void)hipFree(dst);
+    dst = nullptr;
+    if (src.empty()) return DABX_OK;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&dst), src.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DABX_OK;
+}
+
+struct StreamHost {
+    int64_t wr = 0;                         // samples pushed
+    DevState st = {};                       // last state read back from the device
+    std::vector<dabx_subch_t> sub;
+    std::vector<dabx::Profile> prof;
+    int msc_bytes = 0;
+};
+
+}  // namespace
+
+struct dabx_ctx {
+    dabx_config_t cfg = {};
+    int bps = 2;                            // bytes per complex sample
+    int ti_slots = 64;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    bool timing = false;
+    float last_ms[5] = {0, 0, 0, 0, 0};
+    int last_frames = 0;
+    bool pending = false;
+
+    // device buffers
+    uint8_t *d_ring = nullptr;
+    DevState *d_state = nullptr;
+    DevSync *d_sync = nullptr;
+    int8_t *d_fic = nullptr, *d_ti = nullptr;
+    uint8_t *d_fib = nullptr, *d_fib_ok = nullptr, *d_msc = nullptr, *d_msc_valid = nullptr;
+    DevSub *d_sub = nullptr;
+    uint32_t *d_info = nullptr;
+    uint32_t *d_prbs = nullptr, *d_scratch = nullptr;
+    DevWork *d_work = nullptr;
+    float2 *d_W = nullptr, *d_nhi = nullptr, *d_nlo = nullptr;
+    int16_t *d_bop = nullptr, *d_nob = nullptr, *d_car = nullptr;
+    int8_t *d_pq = nullptr, *d_pdq = nullptr;
+    int32_t *d_cordic = nullptr;
+    DevState *h_state = nullptr;            // pinned mirror
+
+    std::vector<StreamHost> streams;
+    std::vector<uint32_t> info_pool;        // depuncturing maps, FIC first
+    std::vector<dabx::Profile> pool_prof;
+    std::vector<int> pool_off;
+    std::vector<DevSub> h_sub;
+    bool work_dirty = true;
+    int work_frames = 0, n_short = 0, n_long = 0, lds_words = 0;
+    size_t scratch_words = 0;
+    std::mutex mu;
+
+    DevCtx dev() const
+    {
+        DevCtx c = {};
+        c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car, d_cordic};
+        c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
+        c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
+        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch;
+        c.ring_len = cfg.ring_samples; c.ring_bytes = static_cast<size_t>(cfg.ring_samples) * bps;
+        c.n_streams = cfg.n_streams; c.max_frames = cfg.max_frames; c.ti_slots = ti_slots;
+        c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0;
+        return c;
+    }
+
+    int pool_lookup(const dabx::Profile &p)
+    {
+        for (size_t i = 0; i < pool_prof.size(); ++i)
+            if (pool_prof[i] == p) return pool_off[i];
+        const int off = static_cast<int>(info_pool.size());
+        const auto info = dabx::step_info(p);
+        info_pool.insert(info_pool.end(), info.begin(), info.end());
+        pool_prof.push_back(p);
+        pool_off.push_back(off);
+        return off;
+    }
+};
+
+namespace {
+
+int upload_tables(dabx_ctx *c)
+{
+    std::vector<float2> W(2048), hi(2048), lo(2048);
+    for (int k = 0; k < 2048; ++k) {
+        const double a = 2.0 * M_PI * k / 2048.0, b = 2.0 * M_PI * k / 4194304.0;
+        W[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(-std::sin(a)));
+        hi[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+        lo[k] = make_float2(static_cast<float>(std::cos(b)), static_cast<float>(std::sin(b)));
+    }
+    const auto car = dabx::carrier_of_symbol();
+    const auto pq = dabx::prs_quadrants();
+    std::vector<int16_t> bop(2048), nob(2048, -1), cfo;
+    std::vector<int8_t> vq(pq.begin(), pq.end()), vdq(2048, -1);
+    for (int p = 0; p < 2048; ++p) bop[p] = static_cast<int16_t>(dabx::bin_of_pos(p));
+    for (int n = 0; n < dabx::kCarriers; ++n) nob[car[n] & 2047] = static_cast<int16_t>(n);
+    for (int k = -767; k <= 768; ++k) {
+        if (k == 0 || k == 1) continue;
+        cfo.push_back(static_cast<int16_t>(k));
+        vdq[k & 2047] = static_cast<int8_t>((pq[k & 2047] - pq[(k - 1) & 2047]) & 3);
+    }
+    // round(atan(2^-i) / (2 pi) * 2^32)
+    std::vector<int32_t> cordic = {536870912, 316933406, 167458907, 85004756, 42667331, 21354465, 10679838, 5340245,
+                                   2670163,   1335087,   667544,    333772,   166886,   83443,    41722,    20861,
+                                   10430,     5215,      2608,      1304,     652,      326,      163,      81,
+                                   41,        20,        10,        5};
+    int rc;
+    if ((rc = dev_upload(c->d_W, W)) || (rc = dev_upload(c->d_nhi, hi)) || (rc = dev_upload(c->d_nlo, lo)) ||
+        (rc = dev_upload(c->d_bop, bop)) || (rc = dev_upload(c->d_nob, nob)) || (rc = dev_upload(c->d_car, cfo)) ||
+        (rc = dev_upload(c->d_pq, vq)) || (rc = dev_upload(c->d_pdq, vdq)) || (rc = dev_upload(c->d_cordic, cordic)))
+        return rc;
+    return dev_upload(c->d_prbs, dabx::prbs_words(dabx::kCifBits));
+}
+
+// (re)build the list of Viterbi codewords for a step of n_frames frames
+int build_work(dabx_ctx *c, int n_frames)
+{
+    struct Item { DevWork w; };
+    std::vector<DevWork> shorts, longs;
+    size_t scratch = 0;
+    for (int s = 0; s < c->cfg.n_streams; ++s)
+        for (int f = 0; f < n_frames; ++f) {
+            for (int cw = 0; cw < 4; ++cw) shorts.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cw), -1, 0u, 774u});
+            const auto &sh = c->streams[s];
+            for (int cif = 0; cif < 4; ++cif)
+                for (size_t k = 0; k < sh.prof.size(); ++k) {
+                    const uint32_t ns = static_cast<uint32_t>(sh.prof[k].steps());
+                    DevWork w = {s, static_cast<int16_t>(f), static_cast<int8_t>(cif), static_cast<int8_t>(k), 0u, ns};
+                    if (ns <= kLdsMaxSteps) shorts.push_back(w);
+                    else {
+                        w.scratch = static_cast<uint32_t>(scratch);
+                        scratch += ((ns + 31) >> 5) * 64;
+                        longs.push_back(w);
+                    }
+                }
+        }
+    auto by_len = [](const DevWork &a, const DevWork &b) { return a.nsteps > b.nsteps; };
+    std::stable_sort(shorts.begin(), shorts.end(), by_len);
+    std::stable_sort(longs.begin(), longs.end(), by_len);
+    c->n_short = static_cast<int>(shorts.size());
+    c->n_long = static_cast<int>(longs.size());
+    c->lds_words = shorts.empty() ? 64 : static_cast<int>(((shorts.front().nsteps + 31) >> 5) * 64);
+    std::vector<DevWork> all(shorts);
+    all.insert(all.end(), longs.begin(), longs.end());
+    int rc = dev_upload(c->d_work, all);
+    if (rc) return rc;
+    if (scratch > c->scratch_words) {
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_scratch), scratch * sizeof(uint32_t)));
+        c->scratch_words = scratch;
+    }
+    c->work_frames = n_frames;
+    c->work_dirty = false;
+    return DABX_OK;
+}
+
+int64_t samples_needed(const StreamHost &s, int n_frames)
+{
+    return s.st.pos + static_cast<int64_t>(n_frames + (s.st.locked ? 0 : 1)) * dabx::kTF + 4096;
+}
+
+bool valid_stream(const dabx_ctx *c, int s) { return c && s >= 0 && s < c->cfg.n_streams; }
+
+}  // namespace
+
+extern "C" {
+
+const char *dabx_strerror(int code)
+{
+    switch (code) {
+    case DABX_OK: return "ok";
+    case DABX_E_ARG: return "bad argument";
+    case DABX_E_NODEV: return "HIP device/runtime error";
+    case DABX_E_NOMEM: return "out of device memory";
+    case DABX_E_UNDERRUN: return "not enough samples buffered";
+    case DABX_E_OVERRUN: return "ring overrun";
+    case DABX_E_PROFILE: return "unsupported protection profile";
+    default: return "unknown error";
+    }
+}
+
+int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
+{
+    if (!cfg || !out || cfg->n_streams < 1 || cfg->max_frames < 1 || cfg->max_frames > 60 ||
+        (cfg->fmt != DABX_FMT_U8 && cfg->fmt != DABX_FMT_S16) ||
+        cfg->ring_samples < static_cast<int64_t>(cfg->max_frames + 2) * dabx::kTF)
+        return DABX_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) {
+        std::fprintf(stderr, "dabx: no HIP device %d (found %d) — this library has no CPU path\n", cfg->device, ndev);
+        return DABX_E_NODEV;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    dabx_ctx *c = new (std::nothrow) dabx_ctx;
+    if (!c) return DABX_E_NOMEM;
+    c->cfg = *cfg;
+    c->bps = cfg->fmt == DABX_FMT_U8 ? 2 : 4;
+    c->ti_slots = 16;
+    while (c->ti_slots < 15 + 4 * cfg->max_frames) c->ti_slots *= 2;
+    c->streams.resize(cfg->n_streams);
+    const size_t S = cfg->n_streams, F = cfg->max_frames;
+#define ALLOC(ptr, bytes)                                                         \
+    do {                                                                          \
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&(ptr)), (bytes)));            \
+        HIPCHK(hipMemset((ptr), 0, (bytes)));                                     \
+    } while (0)
+    HIPCHK(hipStreamCreate(&c->stream));
+    for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    ALLOC(c->d_ring, S * static_cast<size_t>(cfg->ring_samples) * c->bps);
+    if (cfg->fmt == DABX_FMT_U8) HIPCHK(hipMemset(c->d_ring, 128, S * static_cast<size_t>(cfg->ring_samples) * c->bps));
+    ALLOC(c->d_state, S * sizeof(DevState));
+    ALLOC(c->d_sync, S * F * sizeof(DevSync));
+    ALLOC(c->d_fic, S * F * DABX_FIC_SOFT_BITS);
+    ALLOC(c->d_ti, S * static_cast<size_t>(c->ti_slots) * DABX_CIF_SOFT_BITS);
+    ALLOC(c->d_fib, S * F * 12 * 32);
+    ALLOC(c->d_fib_ok, S * F * 12);
+    ALLOC(c->d_msc, S * F * 4 * DABX_MSC_STRIDE);
+    ALLOC(c->d_msc_valid, S * F * 4);
+    ALLOC(c->d_sub, S * 64 * sizeof(DevSub));
+#undef ALLOC
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_state), S * sizeof(DevState)));
+    std::memset(c->h_state, 0, S * sizeof(DevState));
+    c->h_sub.assign(S * 64, DevSub{});
+    int rc = upload_tables(c);
+    if (rc) { dabx_destroy(c); return rc; }
+    c->pool_lookup(dabx::fic_profile());                 // offset 0
+    if ((rc = dev_upload(c->d_info, c->info_pool))) { dabx_destroy(c); return rc; }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_viterbi<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               4 * ((kLdsMaxSteps + 31) / 32) * 64 * 4));
+    *out = c;
+    return DABX_OK;
+}
+
+void dabx_destroy(dabx_ctx *c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dabx_set_subchannels(dabx_ctx *c, int s, int n, const dabx_subch_t *sub)
+{
+    if (!valid_stream(c, s) || n < 0 || n > DABX_MAX_SUBCH || (n && !sub)) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->pending) return DABX_E_ARG;
+    std::vector<dabx::Profile> prof(n);
+    std::vector<DevSub> ds(64, DevSub{});
+    int out_off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dabx::eep_profile(sub[i].option, sub[i].level, sub[i].kbps, prof[i])) return DABX_E_PROFILE;
+        if (sub[i].start_cu < 0 || sub[i].start_cu + prof[i].n_cu > dabx::kNumCu) return DABX_E_ARG;
+        ds[i] = {sub[i].start_cu * dabx::kCuBits, prof[i].steps(), prof[i].n_in, c->pool_lookup(prof[i]), out_off};
+        out_off += prof[i].n_in / 8;
+    }
+    if (out_off > DABX_MSC_STRIDE) return DABX_E_ARG;
+    auto &sh = c->streams[s];
+    sh.sub.assign(sub, sub + n);
+    sh.prof = prof;
+    sh.msc_bytes = out_off;
+    std::copy(ds.begin(), ds.end(), c->h_sub.begin() + static_cast<size_t>(s) * 64);
+    HIPCHK(hipMemcpy(c->d_sub + static_cast<size_t>(s) * 64, ds.data(), 64 * sizeof(DevSub), hipMemcpyHostToDevice));
+    int rc = dev_upload(c->d_info, c->info_pool);
+    if (rc) return rc;
+    c->work_dirty = true;
+    return out_off;
+}
+
+int dabx_push(dabx_ctx *c, int s, const void *src, int64_t n, int on_device)
+{
+    if (!valid_stream(c, s) || n < 0 || (n && !src)) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto &sh = c->streams[s];
+    const int64_t len = c->cfg.ring_samples;
+    // samples older than (pos - one frame) are no longer needed by any kernel
+    if (sh.wr + n - (sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
+    uint8_t *ring = c->d_ring + static_cast<size_t>(s) * len * c->bps;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    int64_t done = 0;
+    while (done < n) {
+        const int64_t w = (sh.wr + done) % len, chunk = std::min(n - done, len - w);
+        HIPCHK(hipMemcpyAsync(ring + w * c->bps, static_cast<const uint8_t *>(src) + done * c->bps,
+                              static_cast<size_t>(chunk) * c->bps, kind, c->stream));
+        done += chunk;
+    }
+    if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
+    sh.wr += n;
+    return DABX_OK;
+}
+
+void *dabx_ring_ptr(dabx_ctx *c, int s)
+{
+    if (!valid_stream(c, s)) return nullptr;
+    return c->d_ring + static_cast<size_t>(s) * c->cfg.ring_samples * c->bps;
+}
+
+int dabx_set_write_pos(dabx_ctx *c, int s, int64_t wr)
+{
+    if (!valid_stream(c, s) || wr < 0) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->streams[s].wr = wr;
+    return DABX_OK;
+}
+
+int dabx_frames_available(dabx_ctx *c)
+{
+    if (!c) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int best = c->cfg.max_frames;
+    for (const auto &sh : c->streams) {
+        int n = 0;
+        while (n < c->cfg.max_frames && samples_needed(sh, n + 1) <= sh.wr) ++n;
+        best = std::min(best, n);
+    }
+    return best;
+}
+
+int dabx_process_async(dabx_ctx *c, int n_frames)
+{
+    if (!c || n_frames < 1 || n_frames > c->cfg.max_frames) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->pending) return DABX_E_ARG;
+    for (const auto &sh : c->streams) {
+        if (samples_needed(sh, n_frames) > sh.wr) return DABX_E_UNDERRUN;
+        if (sh.wr - (sh.st.pos - dabx::kTF) > c->cfg.ring_samples && sh.wr < (1LL << 62)) return DABX_E_OVERRUN;
+    }
+    if (c->work_dirty || c->work_frames != n_frames) {
+        int rc = build_work(c, n_frames);
+        if (rc) return rc;
+    }
+    const DevCtx d = c->dev();
+    const int S = c->cfg.n_streams;
+    hipStream_t q = c->stream;
+    const bool u8 = c->cfg.fmt == DABX_FMT_U8;
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[0], q));
+    if (u8) hipLaunchKernelGGL(k_null_search<0>, dim3(S), dim3(256), 0, q, d);
+    else hipLaunchKernelGGL(k_null_search<1>, dim3(S), dim3(256), 0, q, d);
+    if (u8) hipLaunchKernelGGL(k_sync<0>, dim3(S * n_frames), dim3(256), 0, q, d, n_frames);
+    else hipLaunchKernelGGL(k_sync<1>, dim3(S * n_frames), dim3(256), 0, q, d, n_frames);
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[1], q));
+    if (u8) hipLaunchKernelGGL(k_demod<0>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+    else hipLaunchKernelGGL(k_demod<1>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
+    if (c->n_short)
+        hipLaunchKernelGGL(k_viterbi<true>, dim3((c->n_short + 3) / 4), dim3(256), static_cast<size_t>(4) * c->lds_words * 4, q, d,
+                           c->d_work, c->n_short, c->lds_words);
+    if (c->n_long)
+        hipLaunchKernelGGL(k_viterbi<false>, dim3((c->n_long + 3) / 4), dim3(256), 0, q, d, c->d_work + c->n_short, c->n_long, 0);
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[3], q));
+    hipLaunchKernelGGL(k_finish, dim3(S), dim3(256), 0, q, d, n_frames);
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[4], q));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_state, c->d_state, static_cast<size_t>(S) * sizeof(DevState), hipMemcpyDeviceToHost, q));
+    c->pending = true;
+    c->last_frames = n_frames;
+    return DABX_OK;
+}
+
+int dabx_wait(dabx_ctx *c)
+{
+    if (!c) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->pending) return DABX_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < c->cfg.n_streams; ++s) c->streams[s].st = c->h_state[s];
+    if (c->timing) {
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
+        HIPCHK(hipEventElapsedTime(&c->last_ms[4], c->ev[0], c->ev[4]));
+    }
+    c->pending = false;
+    return DABX_OK;
+}
+
+int dabx_process(dabx_ctx *c, int n_frames)
+{
+    int rc = dabx_process_async(c, n_frames);
+    return rc ? rc : dabx_wait(c);
+}
+
+#define GETTER_PROLOGUE                                            \
+    if (!valid_stream(c, s)) return DABX_E_ARG;                    \
+    std::lock_guard<std::mutex> lk(c->mu);                         \
+    if (c->pending) return DABX_E_ARG;                             \
+    const size_t F = c->cfg.max_frames, n = c->last_frames;        \
+    (void)F; (void)n;
+
+int dabx_get_fib(dabx_ctx *c, int s, uint8_t *fib, uint8_t *ok)
+{
+    GETTER_PROLOGUE
+    if (fib) HIPCHK(hipMemcpy(fib, c->d_fib + s * F * 384, n * 384, hipMemcpyDeviceToHost));
+    if (ok) HIPCHK(hipMemcpy(ok, c->d_fib_ok + s * F * 12, n * 12, hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_msc(dabx_ctx *c, int s, uint8_t *msc, uint8_t *valid)
+{
+    GETTER_PROLOGUE
+    const size_t nb = c->streams[s].msc_bytes;
+    if (msc && nb)
+        HIPCHK(hipMemcpy2D(msc, nb, c->d_msc + s * F * 4 * DABX_MSC_STRIDE, DABX_MSC_STRIDE, nb, n * 4, hipMemcpyDeviceToHost));
+    if (valid) HIPCHK(hipMemcpy(valid, c->d_msc_valid + s * F * 4, n * 4, hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_sync(dabx_ctx *c, int s, dabx_sync_rec_t *rec)
+{
+    GETTER_PROLOGUE
+    static_assert(sizeof(dabx_sync_rec_t) == sizeof(DevSync), "sync record layout");
+    if (!rec) return DABX_E_ARG;
+    HIPCHK(hipMemcpy(rec, c->d_sync + s * F, n * sizeof(DevSync), hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_state(dabx_ctx *c, int s, dabx_stream_state_t *st)
+{
+    GETTER_PROLOGUE
+    if (!st) return DABX_E_ARG;
+    const auto &sh = c->streams[s];
+    *st = {sh.st.pos, sh.st.inc, sh.st.locked, sh.st.cif, sh.st.bad, 0, sh.wr};
+    return DABX_OK;
+}
+
+int dabx_get_fic_soft(dabx_ctx *c, int s, int8_t *fic)
+{
+    GETTER_PROLOGUE
+    if (!fic) return DABX_E_ARG;
+    HIPCHK(hipMemcpy(fic, c->d_fic + s * F * DABX_FIC_SOFT_BITS, n * DABX_FIC_SOFT_BITS, hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_msc_soft(dabx_ctx *c, int s, int8_t *msc)
+{
+    GETTER_PROLOGUE
+    if (!msc) return DABX_E_ARG;
+    // the CIFs of the last step sit in rows (cif_end - 4n + k) & (slots-1) of the ring
+    const int64_t cif_end = c->streams[s].st.cif;
+    for (size_t k = 0; k < n * 4; ++k) {
+        const size_t row = static_cast<size_t>((cif_end - static_cast<int64_t>(n * 4) + static_cast<int64_t>(k)) & (c->ti_slots - 1));
+        HIPCHK(hipMemcpy(msc + k * DABX_CIF_SOFT_BITS, c->d_ti + (static_cast<size_t>(s) * c->ti_slots + row) * DABX_CIF_SOFT_BITS,
+                         DABX_CIF_SOFT_BITS, hipMemcpyDeviceToHost));
+    }
+    return DABX_OK;
+}
+
+int dabx_get_fib_counts(dabx_ctx *c, int64_t *ok, int64_t *bad)
+{
+    if (!c) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->pending) return DABX_E_ARG;
+    const size_t S = c->cfg.n_streams, F = c->cfg.max_frames, n = c->last_frames;
+    std::vector<uint8_t> h(S * F * 12);
+    HIPCHK(hipMemcpy(h.data(), c->d_fib_ok, h.size(), hipMemcpyDeviceToHost));
+    int64_t good = 0;
+    for (size_t s = 0; s < S; ++s)
+        for (size_t k = 0; k < n * 12; ++k) good += h[s * F * 12 + k];
+    if (ok) *ok = good;
+    if (bad) *bad = static_cast<int64_t>(S * n * 12) - good;
+    return DABX_OK;
+}
+
+int dabx_fft2048(dabx_ctx *c, const float *in, float *out, int n_vec)
+{
+    if (!c || !in || !out || n_vec < 1) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    float2 *d_in = nullptr, *d_out = nullptr;
+    const size_t bytes = static_cast<size_t>(n_vec) * 2048 * sizeof(float2);
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_in), bytes));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_out), bytes));
+    HIPCHK(hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fft, dim3(n_vec), dim3(256), 0, c->stream, c->dev().tab, d_in, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return DABX_OK;
+}
+
+int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const int8_t *soft, int n_cw, uint8_t *out)
+{
+    if (!c || !soft || !out || n_cw < 1) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    dabx::Profile p = dabx::fic_profile();
+    if (kind != 0 && !dabx::eep_profile(option, level, kbps, p)) return DABX_E_PROFILE;
+    const auto info = dabx::step_info(p);
+    const int nsteps = p.steps();
+    const size_t words = static_cast<size_t>(((nsteps + 31) >> 5) * 64);
+    int8_t *d_soft = nullptr; uint32_t *d_info = nullptr, *d_scr = nullptr; uint8_t *d_out = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_soft), static_cast<size_t>(n_cw) * p.n_coded));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_info), info.size() * 4));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_scr), static_cast<size_t>(n_cw) * words * 4));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_out), static_cast<size_t>(n_cw) * (p.n_in / 8)));
+    HIPCHK(hipMemcpy(d_soft, soft, static_cast<size_t>(n_cw) * p.n_coded, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_info, info.data(), info.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_viterbi_linear, dim3((n_cw + 3) / 4), dim3(256), 0, c->stream, d_soft, p.n_coded, d_info, nsteps, p.n_in,
+                       c->d_prbs, d_scr, d_out, n_cw);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d_out, static_cast<size_t>(n_cw) * (p.n_in / 8), hipMemcpyDeviceToHost));
+    (void)hipFree(d_soft); (void)hipFree(d_info); (void)hipFree(d_scr); (void)hipFree(d_out);
+    return p.n_in / 8;
+}
+
+int dabx_enable_timing(dabx_ctx *c, int on)
+{
+    if (!c) return DABX_E_ARG;
+    c->timing = on != 0;
+    return DABX_OK;
+}
+
+int dabx_last_timing(dabx_ctx *c, float ms[5])
+{
+    if (!c || !ms) return DABX_E_ARG;
+    std::memcpy(ms, c->last_ms, sizeof c->last_ms);
+    return DABX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// dabx_dev.h — device-side data layout shared by the kernels and the host API.
+//
+// HBM layout per context (S = streams, F = max_frames, all arrays stream-major so
+// one workgroup's traffic is contiguous):
+//   ring      [S][ring_samples]            raw IQ, u8 pairs or s16 pairs (the reference's
+//                                           raw-file formats, src/input/rawfileinput.cpp:640-713)
+//   fic_soft  [S][F][9216]        int8      FIC soft bits, frequency de-interleaved
+//   ti        [S][ti_slots][55296] int8     MSC soft bits, one row per CIF: the time
+//                                           de-interleaver ring (>= 15 + 4 F rows)
+//   fib       [S][F][12][32]                decoded FIBs;  fib_ok [S][F][12]
+//   msc       [S][F][4][msc_stride]         decoded sub-channel bytes;  msc_valid [S][F][4]
+//   sync      [S][F]                        per-frame synchronisation records
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+struct DevState {
+    int64_t pos;        // estimated start of the next frame's null symbol
+    int64_t cif;        // CIFs demodulated since lock (ring row = cif & (ti_slots-1))
+    int32_t inc;        // carrier offset, 2^-32 turn per sample
+    int32_t locked;
+    int32_t bad;        // consecutive frames without PRS
+    int32_t acq_fail;   // set by k_null_search for the current step only
+};
+
+struct DevSync {        // same layout as dabx_sync_rec_t
+    int64_t t_sym0;
+    int32_t inc, flags, peak_idx, m_int;
+    float peak, total;
+    int64_t cp_re, cp_im;
+};
+
+struct DevWork {        // one Viterbi codeword = one wave
+    int32_t stream;
+    int16_t frame;
+    int8_t c;           // FIC codeword 0..3 or CIF 0..3
+    int8_t sub;         // -1 = FIC
+    uint32_t scratch;   // offset (in 32-bit words) into dec_scratch for long codewords
+    uint32_t nsteps;
+};
+
+struct DevSub {
+    int32_t start_bit;  // first soft bit of the sub-channel inside a CIF row
+    int32_t nsteps, n_in;
+    int32_t info_off;   // offset into stepinfo
+    int32_t out_off;    // byte offset inside the CIF's output record
+};
+
+struct DevTables {
+    const float2 *W;            // [2048] exp(-j 2 pi k / 2048)
+    const float2 *nco_hi;       // [2048] exp(+j 2 pi k / 2^11)
+    const float2 *nco_lo;       // [2048] exp(+j 2 pi k / 2^22)
+    const int16_t *bin_of_pos;  // [2048] FFT output placement
+    const int16_t *n_of_bin;    // [2048] frequency de-interleaver (-1 unused)
+    const int8_t *prs_q;        // [2048] PRS quadrant (-1 unused)
+    const int8_t *prs_dq;       // [2048] PRS quadrant difference k vs k-1
+    const int16_t *cfo_car;     // [1534] carriers usable for the differential CFO search
+    const int32_t *cordic;      // [28]
+};
+
+struct DevCtx {
+    DevTables tab;
+    DevState *state;
+    DevSync *sync;
+    const uint8_t *ring;
+    int8_t *fic_soft;
+    int8_t *ti;
+    uint8_t *fib, *fib_ok, *msc, *msc_valid;
+    const DevSub *sub;          // [S][64]
+    const uint32_t *stepinfo;   // pooled depuncturing maps
+    const uint32_t *prbs;       // energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
+    uint32_t *dec_scratch;      // decision words of codewords too long for LDS
+    int64_t ring_len;           // samples
+    size_t ring_bytes;          // bytes per stream
+    int32_t n_streams, max_frames, ti_slots, msc_stride, fic_info_off;
+};

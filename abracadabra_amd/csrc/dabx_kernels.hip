@@ -1,0 +1,732 @@
+// dabx_kernels.hip — CDNA4 (gfx950) kernels of the DAB Mode-I PHY decode chain.
+//
+// Replaces the sample-by-sample worker loop inside the reference's closed
+// dabsdr library (reference: lib/linux_x86_64/dabsdr.h:397 `dabsdr()`;
+// observed stage order in SURVEY.md §3.3) with four batched stages over
+// (stream, frame):
+//   k_null_search  frame acquisition on raw sample energy            (integer)
+//   k_sync         guard-interval CFO + PRS impulse-response timing  (integer + f32)
+//   k_demod        2048-point FFT, pi/4-DQPSK demap, frequency de-interleave -> int8
+//   k_viterbi      time de-interleave gather, depuncture, K=7 Viterbi, de-dispersal
+//   k_finish       FIB CRC-16 and per-stream tracking state
+// No MFMA: the FFT is LDS-exchange bound, the Viterbi is VALU/DPP bound.
+//
+// Arithmetic contract: every float operation below is one IEEE
+// binary32 operation in a fixed order; the file is compiled with
+// -ffp-contract=off so results equal the CPU checker bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dabx_dev.h"
+
+namespace {
+
+constexpr int TF = 196608, TNULL = 2656, TS = 2552, TU = 2048, TG = 504;
+constexpr int NSYM = 76, SYMBITS = 3072, NCAR = 1536;
+constexpr int FICBITS = 9216, CIFBITS = 55296;
+constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 17, PM_INIT = -1000000;
+constexpr float LOCK_THR = 48.0f;
+
+struct cf { float r, i; };
+
+__device__ __forceinline__ cf cmul(cf a, cf b)
+{
+    float p0 = a.r * b.r, p1 = a.i * b.i, p2 = a.r * b.i, p3 = a.i * b.r;
+    return {p0 - p1, p2 + p3};
+}
+__device__ __forceinline__ cf cmulc(cf a, cf b)   // a * conj(b)
+{
+    float p0 = a.r * b.r, p1 = a.i * b.i, p2 = a.i * b.r, p3 = a.r * b.i;
+    return {p0 + p1, p2 - p3};
+}
+__device__ __forceinline__ cf rotq(cf x, int q)   // x * exp(-j q pi/2), exact
+{
+    switch (q & 3) {
+    case 0: return x;
+    case 1: return {x.i, -x.r};
+    case 2: return {-x.r, -x.i};
+    default: return {-x.i, x.r};
+    }
+}
+
+// ---- 2048-point FFT: radix 8-8-8-4 decimation in frequency, 256 threads, 8 points each.
+__device__ __forceinline__ void r4(cf &u0, cf &u1, cf &u2, cf &u3)
+{
+    cf p0 = {u0.r + u2.r, u0.i + u2.i}, p1 = {u0.r - u2.r, u0.i - u2.i};
+    cf q0 = {u1.r + u3.r, u1.i + u3.i};
+    float tr = u1.r - u3.r, ti = u1.i - u3.i;
+    cf q1 = {ti, -tr};
+    u0 = {p0.r + q0.r, p0.i + q0.i}; u2 = {p0.r - q0.r, p0.i - q0.i};
+    u1 = {p1.r + q1.r, p1.i + q1.i}; u3 = {p1.r - q1.r, p1.i - q1.i};
+}
+__device__ __forceinline__ void r8(cf v[8])
+{
+    const float c8 = 0.70710678118654752440f;
+    cf a0 = {v[0].r + v[4].r, v[0].i + v[4].i}, b0 = {v[0].r - v[4].r, v[0].i - v[4].i};
+    cf a1 = {v[1].r + v[5].r, v[1].i + v[5].i}, b1 = {v[1].r - v[5].r, v[1].i - v[5].i};
+    cf a2 = {v[2].r + v[6].r, v[2].i + v[6].i}, b2 = {v[2].r - v[6].r, v[2].i - v[6].i};
+    cf a3 = {v[3].r + v[7].r, v[3].i + v[7].i}, b3 = {v[3].r - v[7].r, v[3].i - v[7].i};
+    float t0, t1;
+    t0 = b1.r + b1.i; t1 = b1.i - b1.r; b1 = {c8 * t0, c8 * t1};
+    b2 = {b2.i, -b2.r};
+    t0 = b3.i - b3.r; t1 = b3.r + b3.i; b3 = {c8 * t0, -(c8 * t1)};
+    r4(a0, a1, a2, a3);
+    r4(b0, b1, b2, b3);
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+    v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+
+// LDS index with one pad slot per 32 complex values (keeps the stride-32 and
+// stride-4 passes off a single bank)
+__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
+constexpr int FFT_LDS = 2048 + 64;
+
+struct Twiddles { cf a[7], b[7], c[7]; };          // per-thread constants of passes A, B, C
+
+__device__ __forceinline__ void load_twiddles(Twiddles &tw, const float2 *__restrict__ W, int t)
+{
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+        float2 x = W[t * c], y = W[8 * (t & 31) * c], z = W[64 * (t & 3) * c];
+        tw.a[c - 1] = {x.x, x.y}; tw.b[c - 1] = {y.x, y.y}; tw.c[c - 1] = {z.x, z.y};
+    }
+}
+
+// in: v[j] = x[t + 256 j]; out: v[e] = X[bin_of_pos(8 t + e)].  buf: FFT_LDS float2.
+// The caller must __syncthreads() before the next use of buf.
+__device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twiddles &tw)
+{
+    r8(v);
+#pragma unroll
+    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw.a[c - 1]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) buf[pad(t + 256 * c)] = make_float2(v[c].r, v[c].i);
+    __syncthreads();
+    int base = (t >> 5) * 256 + (t & 31);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 32 * j)]; v[j] = {x.x, x.y}; }
+    r8(v);
+#pragma unroll
+    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw.b[c - 1]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) buf[pad(base + 32 * c)] = make_float2(v[c].r, v[c].i);
+    __syncthreads();
+    base = (t >> 2) * 32 + (t & 3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 4 * j)]; v[j] = {x.x, x.y}; }
+    r8(v);
+#pragma unroll
+    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw.c[c - 1]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].r, v[c].i);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { float2 x = buf[pad(8 * t + e)]; v[e] = {x.x, x.y}; }
+    r4(v[0], v[1], v[2], v[3]);
+    r4(v[4], v[5], v[6], v[7]);
+}
+
+// fixed-order block sum (256 threads): xor butterfly in each wave, then (W0+W1)+(W2+W3)
+__device__ __forceinline__ float reduce256(float x, float *red /*4 floats*/, int t)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) x = x + __shfl_xor(x, d, 64);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = x;
+    __syncthreads();
+    float s01 = red[0] + red[1], s23 = red[2] + red[3];
+    return s01 + s23;
+}
+
+__device__ __forceinline__ cf nco(const DevTables &T, uint32_t th)
+{
+    float2 h = T.nco_hi[th >> 21], l = T.nco_lo[(th >> 10) & 2047];
+    return cmul({h.x, h.y}, {l.x, l.y});
+}
+
+template <int FMT>
+__device__ __forceinline__ void sample(const uint8_t *ring, int64_t idx, int &i, int &q)
+{
+    if (FMT == 0) { uint16_t u = reinterpret_cast<const uint16_t *>(ring)[idx]; i = (int)(u & 0xff) - 128; q = (int)(u >> 8) - 128; }
+    else { uint32_t u = reinterpret_cast<const uint32_t *>(ring)[idx]; i = (int16_t)(u & 0xffff); q = (int16_t)(u >> 16); }
+}
+
+__device__ __forceinline__ int64_t wrap(int64_t n, int64_t len)
+{
+    int64_t w = n % len;
+    return w < 0 ? w + len : w;
+}
+
+// 2048-sample window starting at ring index `widx` (already wrapped), de-rotated
+// by -inc with phase zero `phase_off` samples before the window
+template <int FMT>
+__device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const uint8_t *ring, int64_t ring_len,
+                                            int64_t widx, uint32_t phase_off, int32_t inc, int t)
+{
+    const uint32_t dth = (uint32_t)(-(int64_t)inc);
+    const cf step = nco(T, dth * 256u);
+    cf rot = nco(T, dth * (phase_off + (uint32_t)t));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int64_t idx = widx + t + 256 * j;
+        if (idx >= ring_len) idx -= ring_len;
+        int si, sq;
+        sample<FMT>(ring, idx, si, sq);
+        if (j) rot = cmul(rot, step);
+        v[j] = cmul({(float)si, (float)sq}, rot);
+    }
+}
+
+// integer CORDIC, angle of (x + j y) in 2^-32 turns
+__device__ int32_t cordic(int64_t y, int64_t x, const int32_t *tab)
+{
+    if (x == 0 && y == 0) return 0;
+    uint64_t ax = (uint64_t)(x < 0 ? -x : x), ay = (uint64_t)(y < 0 ? -y : y), m = ax > ay ? ax : ay;
+    int sh = 0;
+    while ((m >> sh) >= (1ULL << 29)) sh++;
+    if (sh) { x >>= sh; y >>= sh; }
+    else while ((m << 1) < (1ULL << 29)) { m <<= 1; x *= 2; y *= 2; }
+    uint32_t ang = 0;
+    if (x < 0) { x = -x; y = -y; ang = 0x80000000u; }
+    for (int i = 0; i < 28; i++) {
+        int64_t xs = x >> i, ys = y >> i;
+        if (y > 0) { x += ys; y -= xs; ang += (uint32_t)tab[i]; }
+        else       { x -= ys; y += xs; ang -= (uint32_t)tab[i]; }
+    }
+    return (int32_t)ang;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ null search
+// One workgroup per stream; acts only on streams that are not locked.
+constexpr int NS_BLOCKS = 3072, NS_WIN = 41;
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_null_search(DevCtx C)
+{
+    const int s = blockIdx.x, t = threadIdx.x;
+    DevState &st = C.state[s];
+    if (st.locked) return;
+    __shared__ uint64_t E[NS_BLOCKS + NS_WIN];
+    __shared__ uint64_t redv[256];
+    __shared__ int redi[256];
+    const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
+    const int64_t from = wrap(st.pos, C.ring_len);
+    for (int b = t; b < NS_BLOCKS + NS_WIN; b += 256) {
+        uint64_t e = 0;
+        int64_t idx = from + 64 * (int64_t)b;
+        idx = idx >= C.ring_len ? idx - C.ring_len : idx;
+        idx = idx >= C.ring_len ? idx - C.ring_len : idx;
+        for (int n = 0; n < 64; ++n) {
+            int i, q;
+            sample<FMT>(ring, idx, i, q);
+            e += (uint64_t)(i * i + q * q);
+            if (++idx >= C.ring_len) idx -= C.ring_len;
+        }
+        E[b] = e;
+    }
+    __syncthreads();
+    uint64_t tot = 0, best = ~0ULL;
+    int bb = 0;
+    for (int b = t; b < NS_BLOCKS; b += 256) {
+        uint64_t m = 0;
+        for (int j = 0; j < NS_WIN; ++j) m += E[b + j];
+        if (m < best) { best = m; bb = b; }
+        tot += E[b];
+    }
+    redv[t] = best; redi[t] = bb;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (t < d) {
+            uint64_t o = redv[t + d]; int oi = redi[t + d];
+            if (o < redv[t] || (o == redv[t] && oi < redi[t])) { redv[t] = o; redi[t] = oi; }
+        }
+        __syncthreads();
+    }
+    best = redv[0]; bb = redi[0];
+    __syncthreads();
+    redv[t] = tot;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (t < d) redv[t] += redv[t + d]; __syncthreads(); }
+    tot = redv[0];
+    if (t == 0) {
+        if (!(best * 4 * NS_BLOCKS < tot * NS_WIN)) { st.acq_fail = 1; return; }
+        int edge = bb + NS_WIN;
+        for (int b = bb; b + 1 < NS_BLOCKS + NS_WIN; ++b)
+            if (E[b] * 2 * NS_BLOCKS > tot && E[b + 1] * 2 * NS_BLOCKS > tot) { edge = b; break; }
+        st.pos = st.pos + 64 * (int64_t)edge - TNULL;
+        st.cif = 0;
+        st.acq_fail = 0;
+    }
+}
+
+// ------------------------------------------------------------------------- sync
+// One workgroup per (stream, frame): guard correlation -> fractional CFO, PRS FFT,
+// optional integer-CFO search, impulse response peak -> window position.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
+{
+    const int s = blockIdx.x / n_frames, f = blockIdx.x % n_frames, t = threadIdx.x;
+    const DevState &st = C.state[s];
+    DevSync &rec = C.sync[(size_t)s * C.max_frames + f];
+    if (st.acq_fail) {
+        if (t == 0) { DevSync z = {}; rec = z; }
+        return;
+    }
+    __shared__ float2 buf[FFT_LDS];
+    __shared__ float2 nat[TU];
+    __shared__ float red[4];
+    __shared__ int64_t red64[8];
+    __shared__ int32_t sh_inc;
+    __shared__ float pk_v[4];
+    __shared__ int pk_i[4];
+    const DevTables &T = C.tab;
+    const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
+    const int wide = !st.locked;
+    const int64_t pos_f = st.pos + (int64_t)f * TF;
+
+    // 1. guard-interval correlation over the PRS and the three FIC symbols
+    int64_t cre = 0, cim = 0;
+    {
+        const int64_t g0 = wrap(pos_f + TNULL, C.ring_len);
+        for (int k = t; k < 4 * 408; k += 256) {
+            int sy = k / 408, n = 48 + k % 408;
+            int64_t a = g0 + (int64_t)sy * TS + n;
+            if (a >= C.ring_len) a -= C.ring_len;
+            int64_t b = a + TU;
+            if (b >= C.ring_len) b -= C.ring_len;
+            int i1, q1, i2, q2;
+            sample<FMT>(ring, a, i1, q1); sample<FMT>(ring, b, i2, q2);
+            cre += (int64_t)i1 * i2 + (int64_t)q1 * q2;
+            cim += (int64_t)q1 * i2 - (int64_t)i1 * q2;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { cre += __shfl_xor(cre, d, 64); cim += __shfl_xor(cim, d, 64); }
+        if ((t & 63) == 0) { red64[2 * (t >> 6)] = cre; red64[2 * (t >> 6) + 1] = cim; }
+        __syncthreads();
+        cre = red64[0] + red64[2] + red64[4] + red64[6];
+        cim = red64[1] + red64[3] + red64[5] + red64[7];
+    }
+    if (t == 0) {
+        int32_t A = cordic(cim, cre, T.cordic);
+        int32_t inc_meas = (int32_t)((-(int64_t)A) >> 11);
+        int32_t inc = inc_meas;
+        if (!wide) {
+            int32_t d = (int32_t)(((uint32_t)(inc_meas - st.inc) + (1u << 20)) & ((1u << 21) - 1)) - (1 << 20);
+            inc = st.inc + d;
+        }
+        sh_inc = inc;
+    }
+    __syncthreads();
+    int32_t inc = sh_inc;
+
+    Twiddles tw;
+    load_twiddles(tw, T.W, t);
+    const int64_t w0 = pos_f + TNULL + TG - BACKOFF;
+    const int64_t w0i = wrap(w0, C.ring_len);
+    cf v[8];
+    load_window<FMT>(v, T, ring, C.ring_len, w0i, 0u, inc, t);
+    fft2048(v, buf, t, tw);
+    int m_best = 0;
+    if (wide) {
+        // spectrum to natural order for the shifted differential correlation
+#pragma unroll
+        for (int e = 0; e < 8; ++e) nat[T.bin_of_pos[8 * t + e]] = make_float2(v[e].r, v[e].i);
+        __syncthreads();
+        float best = -1.0f;
+        for (int m = -CFO_RANGE; m <= CFO_RANGE; ++m) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int i = 0; i < 6; ++i) {
+                int j = t + 256 * i;
+                if (j >= 1534) break;
+                int k = T.cfo_car[j];
+                float2 x1 = nat[(k + m) & 2047], x0 = nat[(k + m - 1) & 2047];
+                cf d = cmulc({x1.x, x1.y}, {x0.x, x0.y});
+                cf e = rotq(d, T.prs_dq[k & 2047]);
+                ar = ar + e.r; ai = ai + e.i;
+            }
+            float cr = reduce256(ar, red, t);
+            float ci = reduce256(ai, red, t);
+            float c0 = cr * cr, c1 = ci * ci, cm = c0 + c1;
+            if (cm > best) { best = cm; m_best = m; }
+        }
+        inc = inc + m_best * (1 << 21);
+        __syncthreads();
+        load_window<FMT>(v, T, ring, C.ring_len, w0i, 0u, inc, t);
+        fft2048(v, buf, t, tw);
+    }
+    // 3. conj(X * conj(P)) in natural order, second FFT -> impulse response
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int b = T.bin_of_pos[8 * t + e];
+        int q = T.prs_q[b];
+        cf r = {0.0f, 0.0f};
+        if (q >= 0) r = rotq(v[e], q);
+        nat[b] = make_float2(r.r, -r.i);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { float2 x = nat[t + 256 * j]; v[j] = {x.x, x.y}; }
+    __syncthreads();
+    fft2048(v, buf, t, tw);
+    float acc = 0.0f, peak = -1.0f;
+    int pidx = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = v[e].r * v[e].r, b = v[e].i * v[e].i, m2 = a + b;
+        acc = acc + m2;
+        int n = T.bin_of_pos[8 * t + e];
+        if (m2 > peak || (m2 == peak && n < pidx)) { peak = m2; pidx = n; }
+    }
+    float total = reduce256(acc, red, t);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float op = __shfl_xor(peak, d, 64); int oi = __shfl_xor(pidx, d, 64);
+        if (op > peak || (op == peak && oi < pidx)) { peak = op; pidx = oi; }
+    }
+    if ((t & 63) == 0) { pk_v[t >> 6] = peak; pk_i[t >> 6] = pidx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (pk_v[w] > peak || (pk_v[w] == peak && pk_i[w] < pidx)) { peak = pk_v[w]; pidx = pk_i[w]; }
+        int delta = pidx >= 1024 ? pidx - 2048 : pidx;
+        DevSync r;
+        r.t_sym0 = w0 + delta - BACKOFF;
+        r.inc = inc;
+        r.flags = ((peak * 2048.0f >= LOCK_THR * total) ? 1 : 0) | (wide ? 2 : 0);
+        r.peak_idx = pidx; r.m_int = m_best;
+        r.peak = peak; r.total = total;
+        r.cp_re = cre; r.cp_im = cim;
+        rec = r;
+    }
+}
+
+// ------------------------------------------------------------------------ demod
+// One workgroup per (stream, frame, group of 19 symbols).  The previous symbol's
+// spectrum stays in registers (same thread owns the same bins in every symbol).
+constexpr int DEMOD_GROUPS = 4, DEMOD_GSYMS = 19;
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_demod(DevCtx C, int n_frames)
+{
+    const int g = blockIdx.x % DEMOD_GROUPS;
+    const int sf = blockIdx.x / DEMOD_GROUPS;
+    const int s = sf / n_frames, f = sf % n_frames, t = threadIdx.x;
+    const DevState &st = C.state[s];
+    if (st.acq_fail) return;
+    const DevSync rec = C.sync[(size_t)s * C.max_frames + f];
+    const DevTables &T = C.tab;
+    __shared__ float2 buf[FFT_LDS];
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) int8_t soft[SYMBITS];
+    const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
+    int8_t *fic = C.fic_soft + ((size_t)s * C.max_frames + f) * FICBITS;
+    int8_t *ti = C.ti + (size_t)s * C.ti_slots * CIFBITS;
+    const int64_t cif0 = st.cif + 4 * (int64_t)f;
+
+    Twiddles tw;
+    load_twiddles(tw, T.W, t);
+    int nidx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) nidx[e] = T.n_of_bin[T.bin_of_pos[8 * t + e]];
+
+    const int l_first = g * DEMOD_GSYMS;                 // first symbol to demap (0 = PRS: reference only)
+    const int l_ref = l_first == 0 ? 0 : l_first - 1;    // symbol whose spectrum seeds the differential
+    const int l_last = l_first + DEMOD_GSYMS - 1;
+    int64_t widx = wrap(rec.t_sym0 + (int64_t)l_ref * TS, C.ring_len);
+    cf prev[8], v[8];
+    for (int l = l_ref; l <= l_last; ++l) {
+        load_window<FMT>(v, T, ring, C.ring_len, widx, (uint32_t)(l * TS), rec.inc, t);
+        widx += TS;
+        if (widx >= C.ring_len) widx -= C.ring_len;
+        fft2048(v, buf, t, tw);
+        if (l > l_ref) {
+            cf y[8];
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                y[e] = cmulc(v[e], prev[e]);
+                if (nidx[e] >= 0) { float a = fabsf(y[e].r) + fabsf(y[e].i); acc = acc + a; }
+            }
+            float S = reduce256(acc, red, t), gsc = 0.0f;
+            if (S > 0.0f && S < __builtin_inff()) { int E; frexpf(S, &E); gsc = ldexpf(1.0f, SOFT_EXP - E); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (nidx[e] >= 0) {
+                    float a = rintf(y[e].r * gsc), b = rintf(y[e].i * gsc);
+                    a = fminf(fmaxf(a, -127.0f), 127.0f); b = fminf(fmaxf(b, -127.0f), 127.0f);
+                    soft[nidx[e]] = (int8_t)a; soft[nidx[e] + NCAR] = (int8_t)b;
+                }
+            __syncthreads();
+            int8_t *dst = (l <= 3) ? fic + (l - 1) * SYMBITS
+                                   : ti + (size_t)((cif0 + (l - 4) / 18) & (C.ti_slots - 1)) * CIFBITS + ((l - 4) % 18) * SYMBITS;
+            if (t < SYMBITS / 16) reinterpret_cast<int4 *>(dst)[t] = reinterpret_cast<const int4 *>(soft)[t];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) prev[e] = v[e];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------- Viterbi
+// One wave per codeword, one trellis state per lane.  The lane<->state map
+// rotates every step so that the two candidates of a butterfly always sit in
+// lanes that differ by one fixed xor vector of the cycle {1,2,7,8,16,32}:
+// four of the six exchanges are single DPP moves, two go through the LDS
+// crossbar (ds_swizzle / ds_bpermute), none touches LDS memory.
+namespace {
+
+constexpr int XV[6] = {1, 2, 7, 8, 16, 32};
+
+// coordinates of a lane in the basis XV: a0 = b0^b2, a1 = b1^b2, a2..a5 = b2..b5
+__device__ __forceinline__ int lane_coord(int lane, int k)
+{
+    int b2 = (lane >> 2) & 1;
+    if (k == 0) return (lane & 1) ^ b2;
+    if (k == 1) return ((lane >> 1) & 1) ^ b2;
+    return (lane >> k) & 1;
+}
+
+// mother code output nibble (x0 in bit 3) for state (bit 5 newest) and input 0
+__device__ __forceinline__ int conv_out0(int state)
+{
+    const int g[4] = {0133 & 63, 0171 & 63, 0145 & 63, 0133 & 63};
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o = (o << 1) | (__popc(state & g[k]) & 1);
+    return o;
+}
+
+template <int PH>
+__device__ __forceinline__ int exchange(int v, int lane)
+{
+    if (PH == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]  (xor 1)
+    if (PH == 1) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]  (xor 2)
+    if (PH == 2) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);   // row_half_mirror      (xor 7)
+    if (PH == 3) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);   // row_ror:8            (xor 8)
+    if (PH == 4) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                // swap 16 via LDS crossbar
+    return __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v);                  // xor 32
+}
+
+struct VitSrc {
+    const int8_t *base;       // soft bits of coded bit 0 (row 0)
+    int64_t r;                // logical frame index (time de-interleaved) or 0
+    int slot_mask;            // ti_slots-1, or -1 for linear codewords
+};
+
+__device__ __forceinline__ int8_t soft_at(const VitSrc &src, uint32_t i)
+{
+    if (src.slot_mask < 0) return src.base[i];
+    uint32_t d = __builtin_bitreverse32(i) >> 28;              // delay of bit i: bit-reversed (i mod 16)
+    return src.base[(size_t)((src.r + d) & src.slot_mask) * CIFBITS + i];
+}
+
+// packed soft values (x0 in byte 0) of trellis step tau, zero where punctured
+__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *__restrict__ info, int tau, int nsteps)
+{
+    if (tau >= nsteps) return 0;
+    uint32_t w = info[tau], off = w >> 4;
+    int x = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (w & (8u >> j)) { x |= ((int)soft_at(src, off) & 0xff) << (8 * j); ++off; }
+    return x;
+}
+
+// one add-compare-select step.  sig/nsig: per-lane +-1 bytes of this phase's branch
+// (and their negation); xs: the step's four soft values, wave-uniform.
+// The decision (1 = the survivor came from the partner lane) is shifted into `bits`.
+template <int PH>
+__device__ __forceinline__ void acs(int &pm, int sig, int nsig, int xs, int lane, uint32_t &bits)
+{
+    int keep = __builtin_amdgcn_sdot4(sig, xs, pm, false);
+    int send = __builtin_amdgcn_sdot4(nsig, xs, pm, false);
+    int recv = exchange<PH>(send, lane);
+    bits = __builtin_amdgcn_alignbit(bits, (uint32_t)(keep - recv), 31);      // sign bit: recv > keep
+    pm = max(keep, recv);
+}
+
+template <int PH0>
+__device__ __forceinline__ void acs_run(int &pm, const int *sig, const int *nsig, int xcur, int s0, int cnt, int lane,
+                                        uint32_t &bits)
+{
+    // PH0 = phase of step s0; full groups of six, then the remainder
+    int s = 0;
+    for (; s + 6 <= cnt; s += 6) {
+        acs<(PH0 + 0) % 6>(pm, sig[(PH0 + 0) % 6], nsig[(PH0 + 0) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 0), lane, bits);
+        acs<(PH0 + 1) % 6>(pm, sig[(PH0 + 1) % 6], nsig[(PH0 + 1) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 1), lane, bits);
+        acs<(PH0 + 2) % 6>(pm, sig[(PH0 + 2) % 6], nsig[(PH0 + 2) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 2), lane, bits);
+        acs<(PH0 + 3) % 6>(pm, sig[(PH0 + 3) % 6], nsig[(PH0 + 3) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 3), lane, bits);
+        acs<(PH0 + 4) % 6>(pm, sig[(PH0 + 4) % 6], nsig[(PH0 + 4) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 4), lane, bits);
+        acs<(PH0 + 5) % 6>(pm, sig[(PH0 + 5) % 6], nsig[(PH0 + 5) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 5), lane, bits);
+    }
+    if (s < cnt) { acs<(PH0 + 0) % 6>(pm, sig[(PH0 + 0) % 6], nsig[(PH0 + 0) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
+    if (s < cnt) { acs<(PH0 + 1) % 6>(pm, sig[(PH0 + 1) % 6], nsig[(PH0 + 1) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
+    if (s < cnt) { acs<(PH0 + 2) % 6>(pm, sig[(PH0 + 2) % 6], nsig[(PH0 + 2) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
+    if (s < cnt) { acs<(PH0 + 3) % 6>(pm, sig[(PH0 + 3) % 6], nsig[(PH0 + 3) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
+    if (s < cnt) { acs<(PH0 + 4) % 6>(pm, sig[(PH0 + 4) % 6], nsig[(PH0 + 4) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
+}
+
+// Decode one terminated codeword with the calling wave.
+//   dec:    32-bit decision words [half-block of 32 steps][64]: the word of the lane
+//           with basis coordinates A is stored at index A, bit 31-j = step j
+//   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
+//   out:    n_in/8 bytes
+__device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
+                             const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    int sig[6], nsig[6];
+#pragma unroll
+    for (int ph = 0; ph < 6; ++ph) {
+        int st = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st |= lane_coord(lane, (i + ph) % 6) << i;
+        int u = st & 1, o = conv_out0(st), sg = 0, ng = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int neg = ((o >> (3 - j)) & 1) ^ u;
+            sg |= (neg ? 0xff : 0x01) << (8 * j);
+            ng |= (neg ? 0x01 : 0xff) << (8 * j);
+        }
+        sig[ph] = sg; nsig[ph] = ng;
+    }
+    const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
+    int pm = lane == 0 ? 0 : PM_INIT;
+    const int nhb = (nsteps + 31) >> 5;                          // half-blocks of 32 steps
+    int xnext = gather_step(src, info, lane, nsteps);
+    int xcur = 0;
+    for (int hb = 0; hb < nhb; ++hb) {
+        if ((hb & 1) == 0) {
+            xcur = xnext;
+            xnext = gather_step(src, info, (hb + 2) * 32 + lane, nsteps);
+        }
+        const int cnt = min(32, nsteps - hb * 32);
+        const int s0 = (hb & 1) * 32;
+        uint32_t bits = 0;
+        switch (hb % 3) {                                        // (32 hb) mod 6 = 2 (hb mod 3)
+        case 0: acs_run<0>(pm, sig, nsig, xcur, s0, cnt, lane, bits); break;
+        case 1: acs_run<2>(pm, sig, nsig, xcur, s0, cnt, lane, bits); break;
+        default: acs_run<4>(pm, sig, nsig, xcur, s0, cnt, lane, bits); break;
+        }
+        dec[hb * 64 + coordA] = bits << (32 - cnt);              // cnt >= 1
+    }
+    // ---- traceback on the scalar unit, in basis coordinates, from state 0
+    uint32_t A = 0;
+    for (int hb = nhb - 1; hb >= 0; --hb) {
+        const uint32_t word = dec[hb * 64 + lane];
+        const int cnt = min(32, nsteps - hb * 32);
+        uint32_t ph = (uint32_t)(hb * 32 + cnt - 1) % 6u;
+        uint32_t o = 0;
+        for (int j = cnt - 1; j >= 0; --j) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)A);
+            const uint32_t d = (w >> (31 - j)) & 1u;
+            o |= ((A >> ph) & 1u) << (31 - j);                   // decoded bit of step 32 hb + j
+            A ^= d << ph;
+            ph = ph == 0 ? 5u : ph - 1u;
+        }
+        const int nb = n_in - hb * 32;                           // n_in is a multiple of 32
+        if (nb > 0 && lane == 0) reinterpret_cast<uint32_t *>(out)[hb] = __builtin_bswap32(o ^ prbs32[hb]);
+    }
+}
+
+}  // namespace
+
+// work item: which codeword a wave decodes
+//   sub < 0: FIC codeword c (0..3) of (stream, frame); else MSC sub-channel `sub` of CIF c
+template <bool LDS_DEC>
+__global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__restrict__ work, int n_work, int lds_words)
+{
+    extern __shared__ uint32_t dec_lds[];
+    const int wave = threadIdx.x >> 6;
+    const int wi = blockIdx.x * 4 + wave;
+    if (wi >= n_work) return;
+    const DevWork w = work[wi];
+    const DevState &st = C.state[w.stream];
+    uint32_t *dec = LDS_DEC ? dec_lds + (size_t)wave * lds_words : C.dec_scratch + w.scratch;
+    if (w.sub < 0) {
+        if (st.acq_fail) return;
+        VitSrc src = {C.fic_soft + ((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304, 0, -1};
+        uint8_t *out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
+        viterbi_wave(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out);
+    } else {
+        const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
+        const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
+        if (r < 0 || st.acq_fail) return;            // time de-interleaver still filling (k_finish flags it)
+        VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + sc.start_bit, r, C.ti_slots - 1};
+        uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
+        viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out);
+    }
+}
+
+// stage-level: n_cw linear codewords of one profile (unit tests, BASELINE config 2 helper)
+__global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int n_coded, const uint32_t *info, int nsteps,
+                                                        int n_in, const uint32_t *prbs, uint32_t *scratch, uint8_t *out, int n_cw)
+{
+    const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wi >= n_cw) return;
+    VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
+    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps + 31) >> 5) * 64), out + (size_t)wi * (n_in / 8));
+}
+
+// stage-level FFT: one workgroup per vector, natural order in and out
+__global__ __launch_bounds__(256) void k_fft(DevTables T, const float2 *in, float2 *out)
+{
+    __shared__ float2 buf[FFT_LDS];
+    const int t = threadIdx.x;
+    Twiddles tw;
+    load_twiddles(tw, T.W, t);
+    cf v[8];
+    for (int j = 0; j < 8; ++j) { float2 x = in[(size_t)blockIdx.x * TU + t + 256 * j]; v[j] = {x.x, x.y}; }
+    fft2048(v, buf, t, tw);
+    for (int e = 0; e < 8; ++e) out[(size_t)blockIdx.x * TU + T.bin_of_pos[8 * t + e]] = make_float2(v[e].r, v[e].i);
+}
+
+// ----------------------------------------------------------------------- finish
+// FIB CRC (one thread per FIB) and the per-stream tracking state for the next step.
+__global__ __launch_bounds__(256) void k_finish(DevCtx C, int n_frames)
+{
+    const int s = blockIdx.x, t = threadIdx.x;
+    DevState &st = C.state[s];
+    for (int k = t; k < n_frames * 12; k += 256) {
+        const uint8_t *fb = C.fib + ((size_t)s * C.max_frames * 12 + k) * 32;
+        uint32_t crc = 0xFFFF;
+        for (int i = 0; i < 30; ++i) {
+            crc ^= (uint32_t)fb[i] << 8;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
+        }
+        crc = ~crc & 0xFFFF;
+        C.fib_ok[(size_t)s * C.max_frames * 12 + k] = (!st.acq_fail && crc == (((uint32_t)fb[30] << 8) | fb[31])) ? 1 : 0;
+    }
+    for (int k = t; k < n_frames * 4; k += 256)
+        C.msc_valid[(size_t)s * C.max_frames * 4 + k] = (!st.acq_fail && st.cif + k - 15 >= 0) ? 1 : 0;
+    __syncthreads();
+    if (t == 0) {
+        if (st.acq_fail) {                    // no null symbol found: skip ahead, stay unlocked
+            st.pos += (int64_t)n_frames * TF;
+            st.acq_fail = 0;
+            return;
+        }
+        const int wide = !st.locked;
+        int nbad = st.bad;
+        for (int f = 0; f < n_frames; ++f) nbad = (C.sync[(size_t)s * C.max_frames + f].flags & 1) ? 0 : nbad + 1;
+        const DevSync &last = C.sync[(size_t)s * C.max_frames + n_frames - 1];
+        st.pos = last.t_sym0 + BACKOFF - TG - TNULL + TF;
+        st.inc = last.inc;
+        st.cif += 4 * (int64_t)n_frames;
+        st.bad = nbad;
+        st.locked = wide ? (nbad == 0) : (nbad < 4);
+    }
+}
+
+// explicit instantiations used by the host side
+template __global__ void k_null_search<0>(DevCtx);
+template __global__ void k_null_search<1>(DevCtx);
+template __global__ void k_sync<0>(DevCtx, int);
+template __global__ void k_sync<1>(DevCtx, int);
+template __global__ void k_demod<0>(DevCtx, int);
+template __global__ void k_demod<1>(DevCtx, int);
+template __global__ void k_viterbi<true>(DevCtx, const DevWork *, int, int);
+template __global__ void k_viterbi<false>(DevCtx, const DevWork *, int, int);

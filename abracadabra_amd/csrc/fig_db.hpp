@@ -1,0 +1,236 @@
+// fig_db.hpp — Fast Information Group database (ETSI EN 300 401 §5.2, §6, §8).
+//
+// Host-side consumer of the FIBs the GPU decodes: collects the multiplex
+// configuration that the reference's dabsdr library reports through
+// dabsdrNtfEnsemble_t, dabsdrServiceListItem_t and dabsdrServiceCompListItem_t
+// (reference: lib/linux_x86_64/dabsdr.h:176-243, :301-318; consumer
+// src/radiocontrol.cpp:1381-1570).  The reference's parser is closed source;
+// this one follows the standard.  Supported: FIG 0/0, 0/1, 0/2, 0/9, 0/10,
+// 0/17, 1/0, 1/1, 1/4.  Unknown FIGs are skipped by their length field.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace figdb {
+
+struct SubChannel {
+    int id = -1, start = -1, size = 0;
+    bool long_form = false;
+    int option = 0, level = 0;        // long form: EEP option 0/1, protection level 1..4
+    int uep_index = -1;               // short form: table index
+    int kbps = 0;
+};
+
+struct Component {
+    int tmid = 0;
+    int ascty_dscty = 0;
+    int subch = -1;                   // stream modes
+    int scid = -1;                    // packet mode
+    bool primary = false, ca = false;
+    int scids = -1;                   // from FIG 0/8, else position
+    std::string label;
+    uint16_t label_flag = 0;
+};
+
+struct Service {
+    uint32_t sid = 0;
+    bool data = false;                // P/D
+    int caid = 0;
+    std::vector<Component> comp;
+    std::string label;
+    uint16_t label_flag = 0;
+    int pty = -1;
+};
+
+struct Ensemble {
+    int eid = -1, ecc = 0, lto = 0, int_table = 0, alarm = 0;
+    int cif_count = -1;
+    std::string label;
+    uint16_t label_flag = 0;
+    uint32_t mjd = 0; int hours = 0, minutes = 0, seconds = 0, ms = 0; bool utc_valid = false;
+};
+
+class Database {
+public:
+    Ensemble ens;
+    std::map<int, SubChannel> subch;
+    std::map<uint32_t, Service> services;
+    int fibs_seen = 0;
+
+    void clear() { *this = Database(); }
+
+    // one FIB of 32 bytes whose CRC has already been verified
+    void parse_fib(const uint8_t *fib)
+    {
+        ++fibs_seen;
+        int pos = 0;
+        while (pos < 30) {
+            const uint8_t head = fib[pos];
+            if (head == 0xFF) break;
+            const int type = head >> 5, len = head & 0x1F;
+            if (len == 0 || pos + 1 + len > 30) break;
+            const uint8_t *d = fib + pos + 1;
+            if (type == 0) fig0(d, len);
+            else if (type == 1) fig1(d, len);
+            pos += 1 + len;
+        }
+    }
+
+    bool ensemble_ready() const { return ens.eid >= 0 && !ens.label.empty(); }
+
+    const Service *find_service(uint32_t sid) const
+    {
+        auto it = services.find(sid);
+        return it == services.end() ? nullptr : &it->second;
+    }
+
+    // bit rate of an EEP sub-channel from its size (§6.2.1 table 7/8)
+    static int eep_kbps(int option, int level, int size)
+    {
+        static const int a_div[5] = {0, 12, 8, 6, 4}, b_div[5] = {0, 27, 21, 18, 15};
+        if (level < 1 || level > 4) return 0;
+        return option == 0 ? 8 * size / a_div[level] : (option == 1 ? 32 * size / b_div[level] : 0);
+    }
+
+private:
+    void fig0(const uint8_t *d, int len)
+    {
+        const bool pd = (d[0] >> 5) & 1;
+        const int ext = d[0] & 0x1F;
+        const uint8_t *p = d + 1;
+        int n = len - 1;
+        switch (ext) {
+        case 0:
+            if (n >= 4) {
+                ens.eid = (p[0] << 8) | p[1];
+                ens.alarm = (p[2] >> 5) & 1;
+                ens.cif_count = (p[2] & 0x1F) * 250 + p[3];
+            }
+            break;
+        case 1:
+            while (n >= 3) {
+                SubChannel s;
+                s.id = p[0] >> 2;
+                s.start = ((p[0] & 3) << 8) | p[1];
+                s.long_form = (p[2] >> 7) & 1;
+                if (s.long_form) {
+                    if (n < 4) return;
+                    s.option = (p[2] >> 4) & 7;
+                    s.level = ((p[2] >> 2) & 3) + 1;
+                    s.size = ((p[2] & 3) << 8) | p[3];
+                    s.kbps = eep_kbps(s.option, s.level, s.size);
+                    p += 4; n -= 4;
+                } else {
+                    s.uep_index = p[2] & 0x3F;
+                    p += 3; n -= 3;
+                }
+                subch[s.id] = s;
+            }
+            break;
+        case 2:
+            while (n >= (pd ? 5 : 3)) {
+                uint32_t sid;
+                if (pd) { sid = (uint32_t(p[0]) << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; p += 4; n -= 4; }
+                else { sid = (p[0] << 8) | p[1]; p += 2; n -= 2; }
+                const int caid = (p[0] >> 4) & 7, ncomp = p[0] & 0xF;
+                ++p; --n;
+                if (n < 2 * ncomp) return;
+                Service &sv = services[sid];
+                sv.sid = sid; sv.data = pd; sv.caid = caid;
+                std::vector<Component> comps;
+                for (int i = 0; i < ncomp; ++i, p += 2, n -= 2) {
+                    Component c;
+                    c.tmid = p[0] >> 6;
+                    if (c.tmid == 3) {
+                        c.scid = ((p[0] & 0x3F) << 6) | (p[1] >> 2);
+                    } else {
+                        c.ascty_dscty = p[0] & 0x3F;
+                        c.subch = p[1] >> 2;
+                    }
+                    c.primary = (p[1] >> 1) & 1;
+                    c.ca = p[1] & 1;
+                    c.scids = i;
+                    comps.push_back(c);
+                }
+                // keep labels of components already known
+                for (size_t i = 0; i < comps.size() && i < sv.comp.size(); ++i) {
+                    comps[i].label = sv.comp[i].label;
+                    comps[i].label_flag = sv.comp[i].label_flag;
+                }
+                sv.comp = comps;
+            }
+            break;
+        case 9:
+            if (n >= 3) {
+                const int v = p[0] & 0x1F;
+                ens.lto = (p[0] & 0x20) ? -v : v;
+                ens.ecc = p[1];
+                ens.int_table = p[2];
+            }
+            break;
+        case 10:
+            if (n >= 4) {
+                ens.mjd = ((uint32_t(p[0]) & 0x7F) << 10) | (uint32_t(p[1]) << 2) | (p[2] >> 6);
+                const bool utc_long = (p[2] >> 3) & 1;
+                ens.hours = ((p[2] & 7) << 2) | (p[3] >> 6);
+                ens.minutes = p[3] & 0x3F;
+                ens.seconds = ens.ms = 0;
+                if (utc_long && n >= 6) { ens.seconds = p[4] >> 2; ens.ms = ((p[4] & 3) << 8) | p[5]; }
+                ens.utc_valid = true;
+            }
+            break;
+        case 17:
+            while (n >= 4) {
+                const uint32_t sid = (p[0] << 8) | p[1];
+                auto it = services.find(sid);
+                if (it != services.end()) it->second.pty = p[3] & 0x1F;
+                p += 4; n -= 4;
+            }
+            break;
+        default: break;
+        }
+    }
+
+    static std::string label16(const uint8_t *c)
+    {
+        std::string s(reinterpret_cast<const char *>(c), 16);
+        return s;
+    }
+
+    void fig1(const uint8_t *d, int len)
+    {
+        const int ext = d[0] & 7;
+        const uint8_t *p = d + 1;
+        const int n = len - 1;
+        if (ext == 0 && n >= 20) {
+            const int eid = (p[0] << 8) | p[1];
+            if (ens.eid < 0 || ens.eid == eid) { ens.label = label16(p + 2); ens.label_flag = uint16_t((p[18] << 8) | p[19]); }
+        } else if (ext == 1 && n >= 20) {
+            const uint32_t sid = (p[0] << 8) | p[1];
+            Service &sv = services[sid];
+            sv.sid = sid;
+            sv.label = label16(p + 2);
+            sv.label_flag = uint16_t((p[18] << 8) | p[19]);
+        } else if (ext == 5 && n >= 22) {
+            const uint32_t sid = (uint32_t(p[0]) << 24) | (p[1] << 16) | (p[2] << 8) | p[3];
+            Service &sv = services[sid];
+            sv.sid = sid; sv.data = true;
+            sv.label = label16(p + 4);
+            sv.label_flag = uint16_t((p[20] << 8) | p[21]);
+        } else if (ext == 4 && n >= 21) {
+            const bool pd = (p[0] >> 7) & 1;
+            const int scids = p[0] & 0xF;
+            if (pd) return;
+            const uint32_t sid = (p[1] << 8) | p[2];
+            auto it = services.find(sid);
+            if (it == services.end()) return;
+            for (auto &c : it->second.comp)
+                if (c.scids == scids) { c.label = label16(p + 3); c.label_flag = uint16_t((p[19] << 8) | p[20]); }
+        }
+    }
+};
+
+}  // namespace figdb

@@ -1,0 +1,213 @@
+"""ctypes view of include/dabx.h (the batch C ABI of libdabsdr_amd.so)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FRAME_SAMPLES = 196608
+FIC_SOFT_BITS = 9216
+CIF_SOFT_BITS = 55296
+MSC_STRIDE = 6912
+
+SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("peak_idx", "<i4"),
+                       ("m_int", "<i4"), ("peak", "<f4"), ("total", "<f4"), ("cp_re", "<i8"), ("cp_im", "<i8")])
+
+# every symbol include/dabx.h declares; tests check that the library exports them all
+DABX_SYMBOLS = [
+    "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_ring_ptr",
+    "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
+    "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
+    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing",
+]
+
+
+class DabxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("n_streams", C.c_int32), ("fmt", C.c_int32), ("ring_samples", C.c_int64),
+                ("max_frames", C.c_int32), ("device", C.c_int32)]
+
+
+class SubCh(C.Structure):
+    _fields_ = [("start_cu", C.c_int32), ("option", C.c_int32), ("level", C.c_int32), ("kbps", C.c_int32)]
+
+
+class StreamState(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("inc", C.c_int32), ("locked", C.c_int32), ("cif", C.c_int64),
+                ("bad", C.c_int32), ("reserved", C.c_int32), ("wr", C.c_int64)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libdabsdr_amd.so")
+
+
+def build_library():
+    """Compile csrc/ for gfx950 with hipcc (works without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def load_library():
+    """Load libdabsdr_amd.so.  There is no fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise DabxError(f"{path} is missing: build it with `make -C abracadabra_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.dabx_strerror.restype = C.c_char_p
+    L.dabx_strerror.argtypes = [C.c_int]
+    L.dabx_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.dabx_destroy.argtypes = [C.c_void_p]
+    L.dabx_destroy.restype = None
+    L.dabx_set_subchannels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dabx_push.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]
+    L.dabx_ring_ptr.restype = C.c_void_p
+    L.dabx_ring_ptr.argtypes = [C.c_void_p, C.c_int]
+    L.dabx_set_write_pos.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    for name in ("dabx_process", "dabx_process_async"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+    L.dabx_wait.argtypes = [C.c_void_p]
+    L.dabx_frames_available.argtypes = [C.c_void_p]
+    for name in ("dabx_get_fib", "dabx_get_msc"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for name in ("dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.dabx_get_fib_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.dabx_fft2048.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.dabx_viterbi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.dabx_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.dabx_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    _LIB = L
+    return L
+
+
+def _chk(rc):
+    if rc < 0:
+        raise DabxError(f"dabx error {rc}: {load_library().dabx_strerror(rc).decode()}")
+    return rc
+
+
+class Context:
+    """A batch decoder over n_streams independent raw-IQ streams on one GPU."""
+
+    def __init__(self, n_streams, fmt=0, ring_frames=16, max_frames=4, device=0):
+        self.L = load_library()
+        self.n_streams, self.fmt, self.max_frames = n_streams, fmt, max_frames
+        self.ring_samples = ring_frames * FRAME_SAMPLES
+        cfg = Config(n_streams, fmt, self.ring_samples, max_frames, device)
+        h = C.c_void_p()
+        _chk(self.L.dabx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.msc_bytes = [0] * n_streams
+        self.last_frames = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dabx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_subchannels(self, stream, subch):
+        arr = (SubCh * max(len(subch), 1))()
+        for i, s in enumerate(subch):
+            arr[i] = SubCh(*[int(v) for v in s])
+        self.msc_bytes[stream] = _chk(self.L.dabx_set_subchannels(self.h, stream, len(subch), arr))
+        return self.msc_bytes[stream]
+
+    def push(self, stream, iq):
+        iq = np.ascontiguousarray(iq)
+        _chk(self.L.dabx_push(self.h, stream, iq.ctypes.data, iq.size // 2, 0))
+
+    def push_device(self, stream, dev_ptr, n_samples):
+        _chk(self.L.dabx_push(self.h, stream, C.c_void_p(dev_ptr), n_samples, 1))
+
+    def ring_ptr(self, stream):
+        return self.L.dabx_ring_ptr(self.h, stream)
+
+    def set_write_pos(self, stream, wr):
+        _chk(self.L.dabx_set_write_pos(self.h, stream, wr))
+
+    def frames_available(self):
+        return _chk(self.L.dabx_frames_available(self.h))
+
+    def process(self, n_frames):
+        _chk(self.L.dabx_process(self.h, n_frames))
+        self.last_frames = n_frames
+
+    def process_async(self, n_frames):
+        _chk(self.L.dabx_process_async(self.h, n_frames))
+        self.last_frames = n_frames
+
+    def wait(self):
+        _chk(self.L.dabx_wait(self.h))
+
+    def fib(self, stream):
+        n = self.last_frames
+        fib = np.zeros((n, 12, 32), dtype=np.uint8)
+        ok = np.zeros((n, 12), dtype=np.uint8)
+        _chk(self.L.dabx_get_fib(self.h, stream, fib.ctypes.data, ok.ctypes.data))
+        return fib, ok
+
+    def msc(self, stream):
+        n = self.last_frames
+        msc = np.zeros((n, 4, max(self.msc_bytes[stream], 1)), dtype=np.uint8)
+        valid = np.zeros((n, 4), dtype=np.uint8)
+        _chk(self.L.dabx_get_msc(self.h, stream, msc.ctypes.data, valid.ctypes.data))
+        return msc[:, :, :self.msc_bytes[stream]], valid
+
+    def sync(self, stream):
+        rec = np.zeros(self.last_frames, dtype=SYNC_DTYPE)
+        _chk(self.L.dabx_get_sync(self.h, stream, rec.ctypes.data))
+        return rec
+
+    def state(self, stream):
+        st = StreamState()
+        _chk(self.L.dabx_get_state(self.h, stream, C.byref(st)))
+        return dict(pos=st.pos, inc=st.inc, locked=st.locked, cif=st.cif, bad=st.bad, wr=st.wr)
+
+    def fic_soft(self, stream):
+        a = np.zeros((self.last_frames, FIC_SOFT_BITS), dtype=np.int8)
+        _chk(self.L.dabx_get_fic_soft(self.h, stream, a.ctypes.data))
+        return a
+
+    def msc_soft(self, stream):
+        a = np.zeros((self.last_frames, 4, CIF_SOFT_BITS), dtype=np.int8)
+        _chk(self.L.dabx_get_msc_soft(self.h, stream, a.ctypes.data))
+        return a
+
+    def fib_counts(self):
+        ok, bad = C.c_int64(), C.c_int64()
+        _chk(self.L.dabx_get_fib_counts(self.h, C.byref(ok), C.byref(bad)))
+        return ok.value, bad.value
+
+    def fft2048(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64).reshape(-1, 2048)
+        out = np.zeros_like(x)
+        _chk(self.L.dabx_fft2048(self.h, x.ctypes.data, out.ctypes.data, x.shape[0]))
+        return out
+
+    def viterbi(self, soft, kind=0, option=0, level=3, kbps=64):
+        soft = np.ascontiguousarray(soft, dtype=np.int8)
+        n_cw = soft.shape[0]
+        out = np.zeros((n_cw, 8192), dtype=np.uint8)
+        flat = np.zeros(n_cw * 8192, dtype=np.uint8)
+        nb = _chk(self.L.dabx_viterbi(self.h, kind, option, level, kbps, soft.ctypes.data, n_cw, flat.ctypes.data))
+        return flat[:n_cw * nb].reshape(n_cw, nb).copy()
+
+    def enable_timing(self, on=True):
+        _chk(self.L.dabx_enable_timing(self.h, 1 if on else 0))
+
+    def last_timing(self):
+        ms = (C.c_float * 5)()
+        _chk(self.L.dabx_last_timing(self.h, ms))
+        return list(ms)

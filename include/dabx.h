@@ -1,0 +1,154 @@
+/*
+ * dabx.h — batch C ABI of the MI355X DAB Mode-I PHY decode library.
+ *
+ * The reference's dabsdr library decodes ONE ensemble per handle and pulls
+ * samples through a context-free callback (reference:
+ * lib/linux_x86_64/dabsdr.h:387 `dabsdrInputFunc_t`, :397-429 the 24 entry
+ * points; caller src/radiocontrol.cpp:81-93; producer src/input/inputdevice.cpp:70-131).
+ * That shape cannot feed a GPU, so the hot path is exposed here as a batch
+ * interface over many independent raw-IQ streams; include/dabsdr_amd.h keeps the
+ * reference's 24 entry points as an adapter over stream 0 of a one-stream context.
+ *
+ * Every entry point takes plain pointers and sizes.  Device memory is owned by
+ * the context; host pointers are copied in/out on the context's HIP stream.
+ * All functions return 0 on success or a negative DABX_E_* code.
+ */
+#ifndef DABX_H
+#define DABX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DABX_API __attribute__((visibility("default")))
+
+/* Mode I constants visible to callers (ETSI EN 300 401 §14.2) */
+#define DABX_FRAME_SAMPLES   196608     /* 96 ms at 2.048 Msps                          */
+#define DABX_FIBS_PER_FRAME  12
+#define DABX_FIB_BYTES       32
+#define DABX_FIC_SOFT_BITS   9216       /* 3 OFDM symbols                               */
+#define DABX_CIF_SOFT_BITS   55296      /* 864 capacity units x 64 bit                  */
+#define DABX_CIFS_PER_FRAME  4
+#define DABX_MSC_STRIDE      6912       /* bytes reserved per CIF in the MSC output     */
+#define DABX_MAX_SUBCH       64
+
+enum {
+    DABX_OK = 0,
+    DABX_E_ARG = -1,        /* bad argument                                          */
+    DABX_E_NODEV = -2,      /* no HIP device / HIP runtime error                     */
+    DABX_E_NOMEM = -3,
+    DABX_E_UNDERRUN = -4,   /* a stream does not hold enough samples for the request */
+    DABX_E_OVERRUN = -5,    /* push would overwrite samples not yet consumed         */
+    DABX_E_PROFILE = -6,    /* unsupported protection profile                        */
+};
+
+/* sample formats of the reference's raw-file input
+ * (reference: src/input/rawfileinput.cpp:640-713: u8 -> float(v-128), s16 -> float(v)) */
+enum { DABX_FMT_U8 = 0, DABX_FMT_S16 = 1 };
+
+typedef struct {
+    int32_t n_streams;            /* independent ensembles decoded side by side           */
+    int32_t fmt;                  /* DABX_FMT_*                                           */
+    int64_t ring_samples;         /* per-stream IQ ring capacity in complex samples       */
+    int32_t max_frames;           /* largest n_frames dabx_process will be called with    */
+    int32_t device;               /* HIP device ordinal                                   */
+} dabx_config_t;
+
+/* per-frame synchronisation record (one per stream and frame of the last step) */
+typedef struct {
+    int64_t t_sym0;               /* absolute sample index of the PRS FFT window          */
+    int32_t inc;                  /* carrier offset, 2^-32 turn per sample                */
+    int32_t flags;                /* bit0: PRS found (frame ok); bit1: wide search used   */
+    int32_t peak_idx;             /* impulse-response peak position                       */
+    int32_t m_int;                /* integer carrier offset found by the wide search      */
+    float   peak, total;          /* |h|^2 peak and sum                                   */
+    int64_t cp_re, cp_im;         /* guard-interval correlation                           */
+} dabx_sync_rec_t;
+
+typedef struct {
+    int64_t pos;                  /* estimated start of the next frame's null symbol      */
+    int32_t inc;                  /* carrier offset estimate                              */
+    int32_t locked;               /* 0 searching, 1 tracking                              */
+    int64_t cif;                  /* CIFs demodulated since lock                          */
+    int32_t bad;                  /* consecutive frames without PRS                       */
+    int32_t reserved;
+    int64_t wr;                   /* samples pushed so far (host side)                    */
+} dabx_stream_state_t;
+
+/* one sub-channel of the MSC: EEP protection only in this version
+ * (ETSI EN 300 401 §11.3.2); option 0 = set A, 1 = set B; level 1..4 */
+typedef struct {
+    int32_t start_cu;
+    int32_t option;
+    int32_t level;
+    int32_t kbps;
+} dabx_subch_t;
+
+typedef struct dabx_ctx dabx_ctx;
+
+DABX_API int  dabx_create(const dabx_config_t *cfg, dabx_ctx **out);
+DABX_API void dabx_destroy(dabx_ctx *ctx);
+DABX_API const char *dabx_strerror(int code);
+
+/* MSC configuration of one stream (what FIG 0/1 announces).  Returns the number
+ * of decoded bytes per CIF (sub-channels concatenated in the given order). */
+DABX_API int dabx_set_subchannels(dabx_ctx *ctx, int stream, int n, const dabx_subch_t *sub);
+
+/* Append n complex samples (interleaved I,Q in the context's format) to a
+ * stream's ring.  src may be host or device memory (src_on_device != 0).
+ * Replaces the producer side of the reference's global FIFO
+ * (reference: src/input/inputdevice.cpp:30, src/input/rawfileinput.cpp:602-747). */
+DABX_API int dabx_push(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_on_device);
+
+/* Device address of a stream's ring and a way to declare samples resident
+ * without copying (zero-copy producers, and the benchmark's periodic signal). */
+DABX_API void *dabx_ring_ptr(dabx_ctx *ctx, int stream);
+DABX_API int   dabx_set_write_pos(dabx_ctx *ctx, int stream, int64_t wr);
+
+/* Decode n_frames transmission frames on every stream: sync, FFT + DQPSK demap,
+ * de-interleave, Viterbi (FIC and all configured sub-channels), FIB CRC.
+ * This is the hot path that replaces the dabsdr worker loop
+ * (reference: SURVEY.md §3.3; lib/linux_x86_64/dabsdr.h:397 `dabsdr()`).
+ * dabx_process returns when the results are complete; the _async form only
+ * enqueues on the context's HIP stream and dabx_wait completes it. */
+DABX_API int dabx_process(dabx_ctx *ctx, int n_frames);
+DABX_API int dabx_process_async(dabx_ctx *ctx, int n_frames);
+DABX_API int dabx_wait(dabx_ctx *ctx);
+/* frames that can be processed right now on every stream (min over streams) */
+DABX_API int dabx_frames_available(dabx_ctx *ctx);
+
+/* Results of the last step, copied to host memory.
+ *   fib     [n_frames][12][32]   decoded FIBs incl. CRC     (reference: FIB -> FIG database, dabsdr.h:158 fibErrorCntr)
+ *   fib_ok  [n_frames][12]       1 where the FIB CRC matched
+ *   msc     [n_frames][4][bytes_per_cif]  decoded sub-channel bytes   (reference: audio/data callbacks, dabsdr.h:71-96)
+ *   valid   [n_frames][4]        0 while the 16-CIF time de-interleaver is filling */
+DABX_API int dabx_get_fib(dabx_ctx *ctx, int stream, uint8_t *fib, uint8_t *fib_ok);
+DABX_API int dabx_get_msc(dabx_ctx *ctx, int stream, uint8_t *msc, uint8_t *valid);
+DABX_API int dabx_get_sync(dabx_ctx *ctx, int stream, dabx_sync_rec_t *rec);
+DABX_API int dabx_get_state(dabx_ctx *ctx, int stream, dabx_stream_state_t *st);
+/* parity taps: soft bits of the last step, fic [n_frames][9216], msc [n_frames][4][55296] */
+DABX_API int dabx_get_fic_soft(dabx_ctx *ctx, int stream, int8_t *fic);
+DABX_API int dabx_get_msc_soft(dabx_ctx *ctx, int stream, int8_t *msc);
+/* sum over streams and frames of the last step: FIBs with good / bad CRC */
+DABX_API int dabx_get_fib_counts(dabx_ctx *ctx, int64_t *ok, int64_t *bad);
+
+/* Stage-level entry points (BASELINE config "FFT + DQPSK demap kernel only",
+ * and unit parity tests).  Host pointers.
+ *   dabx_fft2048: n_vec vectors of 2048 complex float (re,im interleaved), natural bin order out
+ *   dabx_viterbi: n_cw punctured codewords of one profile, soft bits linear in memory;
+ *                 kind 0 = FIC codeword (2304 soft -> 96 bytes), 1 = EEP(option, level, kbps) */
+DABX_API int dabx_fft2048(dabx_ctx *ctx, const float *in, float *out, int n_vec);
+DABX_API int dabx_viterbi(dabx_ctx *ctx, int kind, int option, int level, int kbps,
+                          const int8_t *soft, int n_cw, uint8_t *out);
+
+/* Timing of the last step, HIP events on the context's stream (ms):
+ * [0] acquire+sync, [1] FFT/demap, [2] Viterbi, [3] CRC/state, [4] whole step */
+DABX_API int dabx_last_timing(dabx_ctx *ctx, float ms[5]);
+DABX_API int dabx_enable_timing(dabx_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
