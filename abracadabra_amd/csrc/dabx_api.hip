@@ -317,7 +317,7 @@ int dabx_push(dabx_ctx *c, int s, const void *src, int64_t n, int on_device)
     auto &sh = c->streams[s];
     const int64_t len = c->cfg.ring_samples;
     // samples older than (pos - one frame) are no longer needed by any kernel
-    if (sh.wr + n - (sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
+    if (sh.wr + n - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
     uint8_t *ring = c->d_ring + static_cast<size_t>(s) * len * c->bps;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     int64_t done = 0;
@@ -366,7 +366,7 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     if (c->pending) return DABX_E_ARG;
     for (const auto &sh : c->streams) {
         if (samples_needed(sh, n_frames) > sh.wr) return DABX_E_UNDERRUN;
-        if (sh.wr - (sh.st.pos - dabx::kTF) > c->cfg.ring_samples && sh.wr < (1LL << 62)) return DABX_E_OVERRUN;
+        if (sh.wr < (1LL << 62) && sh.wr - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > c->cfg.ring_samples) return DABX_E_OVERRUN;
     }
     if (c->work_dirty || c->work_frames != n_frames) {
         int rc = build_work(c, n_frames);

@@ -1,0 +1,148 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+import abracadabra_amd as aa
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fft_bit_exact(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(n_streams=1, max_frames=1, ring_frames=4)
+    rng = np.random.default_rng(0)
+    x = (rng.integers(-32768, 32768, (16, 2048)) + 1j * rng.integers(-32768, 32768, (16, 2048))).astype(np.complex64)
+    g = ctx.fft2048(x)
+    o = np.stack([ob.fft(v) for v in x]).astype(np.complex64)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))       # bit for bit
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    assert np.abs(g - ref).max() <= 2e-6 * np.abs(ref).max()           # and an fp32-accurate DFT
+
+
+@pytest.mark.parametrize("kind,prof", [(0, (0, 3, 64)), (1, (0, 3, 64)), (1, (0, 1, 8)), (1, (0, 2, 8)), (1, (0, 2, 40)),
+                                       (1, (0, 4, 72)), (1, (1, 1, 32)), (1, (1, 2, 64)), (1, (1, 3, 32)), (1, (1, 4, 96)),
+                                       (1, (0, 3, 192))])
+def test_viterbi_bit_exact(gpu_ctx_factory, kind, prof):
+    ctx = gpu_ctx_factory(n_streams=1, max_frames=1, ring_frames=4)
+    n_coded = 2304 if kind == 0 else ob.eep_profile(*prof).n_coded
+    rng = np.random.default_rng(hash(prof) & 0xFFFF)
+    soft = rng.integers(-127, 128, (9, n_coded)).astype(np.int8)
+    soft[1] = 0                                   # all ties
+    soft[2] = rng.integers(-1, 2, n_coded)        # many ties
+    soft[3] = 127                                 # saturated, all-zero codeword
+    g = ctx.viterbi(soft, kind, *prof)
+    o = np.stack([ob.decode_linear(s, kind, *prof) for s in soft])
+    assert np.array_equal(g, o)
+
+
+def _run_pair(ctx, streams, steps, frames, subs):
+    """feed identical input to the GPU context and to one oracle per stream; compare every tap"""
+    oracles = []
+    for s, iq in enumerate(streams):
+        ctx.set_subchannels(s, subs[s])
+        ctx.push(s, iq)
+        o = ob.Stream(fmt=ctx.fmt, subch=subs[s], ring_len=ctx.ring_samples, ti_slots=64)
+        o.push(iq)
+        oracles.append(o)
+    results = []
+    for _ in range(steps):
+        ctx.process(frames)
+        for s, orc in enumerate(oracles):
+            o = orc.process(frames)
+            assert o["rc"] in (0, frames)
+            assert np.array_equal(ctx.sync(s), o["sync"]), f"sync records, stream {s}"
+            gf, gok = ctx.fib(s)
+            assert np.array_equal(gok, o["fib_ok"])
+            if o["rc"]:
+                assert np.array_equal(ctx.fic_soft(s), o["fic_soft"])
+                assert np.array_equal(ctx.msc_soft(s), o["msc_soft"])
+                assert np.array_equal(gf, o["fib"])
+            gm, gv = ctx.msc(s)
+            assert np.array_equal(gv, o["msc_valid"])
+            assert np.array_equal(gm[gv == 1], o["msc"][o["msc_valid"] == 1])
+            st = ctx.state(s)
+            so = orc.state()
+            assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"])
+            results.append((s, gf, gok, gm, gv))
+    return results
+
+
+def test_full_chain_u8_matches_oracle_and_transmitter(gpu_ctx_factory):
+    subs = [ob.subch_layout(18, 64), [[0, 0, 3, 64], [48, 1, 4, 32], [100, 0, 1, 8], [200, 0, 2, 32], [300, 0, 3, 192]]]
+    streams, truth = [], []
+    for s in range(2):
+        iq, fib, msc = ob.tx_generate(seed=20 + s, eid=0x2000 + s, n_frames=10, subch=subs[s], delay=1000 + 77777 * s,
+                                      snr_db=12.0 + 10 * s, cfo_hz=-2345.0 + 5000.0 * s)
+        streams.append(iq); truth.append((fib, msc))
+    ctx = gpu_ctx_factory(n_streams=2, fmt=0, ring_frames=16, max_frames=4)
+    res = _run_pair(ctx, streams, steps=2, frames=4, subs=subs)
+    for i, (s, gf, gok, gm, gv) in enumerate(res):
+        step = i // 2
+        fib, msc = truth[s]
+        assert gok.all() and np.array_equal(gf, fib[4 * step:4 * step + 4])
+        for f in range(4):
+            for c in range(4):
+                if gv[f, c]:
+                    assert np.array_equal(gm[f, c], msc[4 * (4 * step + f) + c - 15])
+
+
+def test_full_chain_s16_and_long_subchannel(gpu_ctx_factory):
+    # one 1152 kbit/s EEP 3-A sub-channel fills all 864 CU: 27654 trellis steps, decisions in HBM scratch
+    sub = [[0, 0, 3, 1152]]
+    iq, fib, msc = ob.tx_generate(seed=31, n_frames=7, subch=sub, delay=4321, fmt=1, snr_db=18.0, cfo_hz=901.0, rms=2500.0)
+    ctx = gpu_ctx_factory(n_streams=1, fmt=1, ring_frames=16, max_frames=3)
+    res = _run_pair(ctx, [iq], steps=2, frames=3, subs=[sub])
+    s, gf, gok, gm, gv = res[-1]
+    assert gok.all() and gv[-1, -1] == 1
+    assert np.array_equal(gm[2, 3], msc[4 * 5 + 3 - 15])
+
+
+def test_noise_stream_next_to_good_stream(gpu_ctx_factory):
+    sub = ob.subch_layout(2, 64)
+    iq, fib, _ = ob.tx_generate(seed=40, n_frames=5, subch=sub, delay=100, snr_db=25.0)
+    rng = np.random.default_rng(2)
+    noise = rng.integers(100, 156, iq.size, dtype=np.uint8)
+    ctx = gpu_ctx_factory(n_streams=2, fmt=0, ring_frames=8, max_frames=2)
+    res = _run_pair(ctx, [noise, iq], steps=1, frames=2, subs=[sub, sub])
+    assert not res[0][2].any() and res[1][2].all()
+    assert ctx.state(0)["locked"] == 0 and ctx.state(1)["locked"] == 1
+
+
+def test_underrun_and_argument_errors(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(n_streams=1, fmt=0, ring_frames=8, max_frames=2)
+    with pytest.raises(aa.DabxError):
+        ctx.process(1)                       # nothing pushed
+    with pytest.raises(aa.DabxError):
+        ctx.process(3)                       # more than max_frames
+    with pytest.raises(aa.DabxError):
+        ctx.set_subchannels(0, [[0, 0, 3, 1160]])     # does not fit 864 CU
+    with pytest.raises(aa.DabxError):
+        ctx.set_subchannels(0, [[0, 0, 5, 64]])       # no such protection level
+    assert ctx.frames_available() == 0
+
+
+def test_periodic_ring_round_trip_at_scale(gpu_ctx_factory):
+    # size-independent property at bench size per stream: every decoded FIB / logical frame of a
+    # looped signal must be one of the transmitted ones, for many steps
+    sub = ob.subch_layout(18, 64)
+    S, P, F = 8, 8, 4
+    ctx = gpu_ctx_factory(n_streams=S, fmt=0, ring_frames=P, max_frames=F)
+    tx = []
+    rng = np.random.default_rng(9)
+    for s in range(S):
+        iq, fib, msc = ob.tx_generate(seed=50 + s, n_frames=P, subch=sub, loop=1, snr_db=15.0, cfo_hz=float(rng.uniform(-3000, 3000)))
+        iq = np.roll(iq.reshape(-1, 2), int(rng.integers(0, ob.TF)), axis=0).reshape(-1)
+        ctx.set_subchannels(s, sub); ctx.push(s, iq); ctx.set_write_pos(s, 1 << 62)
+        tx.append(({f.tobytes() for f in fib}, {m.tobytes() for m in msc}))
+    for step in range(6):
+        ctx.process(F)
+        if step < 4:
+            continue
+        ok, bad = ctx.fib_counts()
+        assert bad == 0 and ok == S * F * 12
+        for s in range(S):
+            gf, _ = ctx.fib(s)
+            gm, gv = ctx.msc(s)
+            assert gv.all()
+            assert all(f.tobytes() in tx[s][0] for f in gf)
+            assert all(m.tobytes() in tx[s][1] for m in gm.reshape(F * 4, -1))

@@ -1,0 +1,61 @@
+"""Transmitter -> oracle receiver round trips on the CPU (small sizes)."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+
+@pytest.mark.parametrize("fmt,snr,cfo,delay", [(0, 30.0, 0.0, 0), (0, 10.0, -2345.0, 5000), (1, 15.0, 7300.5, 150000)])
+def test_fic_roundtrip(fmt, snr, cfo, delay):
+    iq, fib, _ = ob.tx_generate(seed=11, n_frames=4, subch=ob.subch_layout(2, 64), delay=delay, fmt=fmt, snr_db=snr,
+                                cfo_hz=cfo, rms=28.0 if fmt == 0 else 3000.0)
+    s = ob.Stream(fmt=fmt)
+    s.push(iq)
+    o = s.process(2)
+    assert o["rc"] == 2 and o["fib_ok"].all()
+    assert np.array_equal(o["fib"], fib[:2])
+    st = s.state()
+    assert st["locked"] == 1
+    assert abs(st["inc"] / 2**32 * 2.048e6 - cfo) < 6.0            # Hz
+
+
+def test_msc_roundtrip_with_time_interleaver():
+    sub = [[0, 0, 3, 64], [48, 1, 4, 32], [100, 0, 1, 8], [200, 0, 2, 32]]
+    iq, fib, msc = ob.tx_generate(seed=5, n_frames=7, subch=sub, delay=321, snr_db=14.0, cfo_hz=431.0)
+    s = ob.Stream(subch=sub)
+    s.push(iq)
+    o = s.process(5)
+    assert o["rc"] == 5 and o["fib_ok"].all()
+    got = o["msc"].reshape(20, -1)
+    valid = o["msc_valid"].reshape(20)
+    assert valid.tolist() == [0] * 15 + [1] * 5
+    for c in range(15, 20):
+        assert np.array_equal(got[c], msc[c - 15])
+
+
+def test_noise_input_does_not_lock():
+    rng = np.random.default_rng(1)
+    iq = rng.integers(100, 156, 2 * 3 * ob.TF, dtype=np.uint8)
+    s = ob.Stream()
+    s.push(iq)
+    o = s.process(1)
+    assert o["rc"] == 0 and not o["fib_ok"].any() and s.state()["locked"] == 0
+
+
+def test_underrun_is_reported():
+    iq, _, _ = ob.tx_generate(seed=1, n_frames=1)
+    s = ob.Stream()
+    s.push(iq)
+    assert s.process(1)["rc"] == -1
+
+
+def test_periodic_signal_loops():
+    sub = ob.subch_layout(2, 64)
+    iq, fib, msc = ob.tx_generate(seed=2, n_frames=4, subch=sub, loop=1, snr_db=25.0)
+    s = ob.Stream(subch=sub, ring_len=16 * ob.TF)
+    for _ in range(3):
+        s.push(iq)
+    o = s.process(4); o = s.process(4)
+    assert o["fib_ok"].all() and o["msc_valid"].all()
+    tx = {m.tobytes() for m in msc}
+    assert all(m.tobytes() in tx for m in o["msc"].reshape(16, -1))
