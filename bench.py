@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--period", type=int, default=12, help="period of the synthetic signal in frames (multiple of 4)")
     ap.add_argument("--snr", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=208)
     return ap.parse_args()
 
 
