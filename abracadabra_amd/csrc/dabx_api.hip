@@ -478,10 +478,14 @@ int dabx_get_msc_soft(dabx_ctx *c, int s, int8_t *msc)
     if (!msc) return DABX_E_ARG;
     // the CIFs of the last step sit in rows (cif_end - 4n + k) & (slots-1) of the ring
     const int64_t cif_end = c->streams[s].st.cif;
+    std::vector<int8_t> rowbuf(DABX_CIF_SOFT_BITS);
+    constexpr int seg = DABX_CIF_SOFT_BITS / 16;
     for (size_t k = 0; k < n * 4; ++k) {
         const size_t row = static_cast<size_t>((cif_end - static_cast<int64_t>(n * 4) + static_cast<int64_t>(k)) & (c->ti_slots - 1));
-        HIPCHK(hipMemcpy(msc + k * DABX_CIF_SOFT_BITS, c->d_ti + (static_cast<size_t>(s) * c->ti_slots + row) * DABX_CIF_SOFT_BITS,
+        HIPCHK(hipMemcpy(rowbuf.data(), c->d_ti + (static_cast<size_t>(s) * c->ti_slots + row) * DABX_CIF_SOFT_BITS,
                          DABX_CIF_SOFT_BITS, hipMemcpyDeviceToHost));
+        // rows are stored residue-major on the device (dabx_dev.h); hand them out in natural bit order
+        for (int b = 0; b < DABX_CIF_SOFT_BITS; ++b) msc[k * DABX_CIF_SOFT_BITS + b] = rowbuf[(b & 15) * seg + (b >> 4)];
     }
     return DABX_OK;
 }

@@ -6,7 +6,10 @@
 //                                           raw-file formats, src/input/rawfileinput.cpp:640-713)
 //   fic_soft  [S][F][9216]        int8      FIC soft bits, frequency de-interleaved
 //   ti        [S][ti_slots][55296] int8     MSC soft bits, one row per CIF: the time
-//                                           de-interleaver ring (>= 15 + 4 F rows)
+//                                           de-interleaver ring (>= 15 + 4 F rows).  Inside a
+//                                           row bit b sits at (b & 15) * 3456 + (b >> 4)
+//                                           (residue-major): a logical frame reads one residue
+//                                           class from each of 16 rows, so its reads are contiguous
 //   fib       [S][F][12][32]                decoded FIBs;  fib_ok [S][F][12]
 //   msc       [S][F][4][msc_stride]         decoded sub-channel bytes;  msc_valid [S][F][4]
 //   sync      [S][F]                        per-frame synchronisation records

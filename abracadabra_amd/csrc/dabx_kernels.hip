@@ -25,6 +25,7 @@ constexpr int NSYM = 76, SYMBITS = 3072, NCAR = 1536;
 constexpr int FICBITS = 9216, CIFBITS = 55296;
 constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 17, PM_INIT = -1000000;
 constexpr float LOCK_THR = 48.0f;
+constexpr int TI_SEG = CIFBITS / 16;   // bytes per residue class in a residue-major MSC row
 
 struct cf { float r, i; };
 
@@ -456,12 +457,25 @@ __global__ __launch_bounds__(256) void k_demod(DevCtx C, int n_frames)
                 if (nidx[e] >= 0) {
                     float a = rintf(y[e].r * gsc), b = rintf(y[e].i * gsc);
                     a = fminf(fmaxf(a, -127.0f), 127.0f); b = fminf(fmaxf(b, -127.0f), 127.0f);
-                    soft[nidx[e]] = (int8_t)a; soft[nidx[e] + NCAR] = (int8_t)b;
+                    const int n0 = nidx[e], n1 = nidx[e] + NCAR;
+                    if (l <= 3) { soft[n0] = (int8_t)a; soft[n1] = (int8_t)b; }
+                    else {                     // MSC: stage residue-major (3072 = 16 * 192, so (n & 15) is the residue)
+                        soft[(n0 & 15) * (SYMBITS / 16) + (n0 >> 4)] = (int8_t)a;
+                        soft[(n1 & 15) * (SYMBITS / 16) + (n1 >> 4)] = (int8_t)b;
+                    }
                 }
             __syncthreads();
-            int8_t *dst = (l <= 3) ? fic + (l - 1) * SYMBITS
-                                   : ti + (size_t)((cif0 + (l - 4) / 18) & (C.ti_slots - 1)) * CIFBITS + ((l - 4) % 18) * SYMBITS;
-            if (t < SYMBITS / 16) reinterpret_cast<int4 *>(dst)[t] = reinterpret_cast<const int4 *>(soft)[t];
+            if (l <= 3) {
+                int8_t *dst = fic + (l - 1) * SYMBITS;
+                if (t < SYMBITS / 16) reinterpret_cast<int4 *>(dst)[t] = reinterpret_cast<const int4 *>(soft)[t];
+            } else if (t < SYMBITS / 16) {
+                // residue-major row: bit b of the CIF lives at (b & 15) * TI_SEG + (b >> 4); `soft`
+                // was filled in that order (see below), 16 segments of 192 bytes per symbol
+                int8_t *row = ti + (size_t)((cif0 + (l - 4) / 18) & (C.ti_slots - 1)) * CIFBITS;
+                const int res = t / 12, part = t % 12;
+                reinterpret_cast<int4 *>(row + res * TI_SEG + ((l - 4) % 18) * (SYMBITS / 16))[part] =
+                    reinterpret_cast<const int4 *>(soft + res * (SYMBITS / 16))[part];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) prev[e] = v[e];
@@ -510,16 +524,21 @@ __device__ __forceinline__ int exchange(int v, int lane)
 }
 
 struct VitSrc {
-    const int8_t *base;       // soft bits of coded bit 0 (row 0)
+    const int8_t *base;       // soft bits of the codeword's first coded bit (row 0)
     int64_t r;                // logical frame index (time de-interleaved) or 0
     int slot_mask;            // ti_slots-1, or -1 for linear codewords
 };
+
+// MSC rows are stored residue-major (TI_SEG = 55296/16 bytes per residue class of the bit
+// index): logical frame r takes exactly one residue class from each of 16 rows, so this
+// layout makes every (row, residue) read contiguous instead of one byte per 16.
 
 __device__ __forceinline__ int8_t soft_at(const VitSrc &src, uint32_t i)
 {
     if (src.slot_mask < 0) return src.base[i];
     uint32_t d = __builtin_bitreverse32(i) >> 28;              // delay of bit i: bit-reversed (i mod 16)
-    return src.base[(size_t)((src.r + d) & src.slot_mask) * CIFBITS + i];
+    // sub-channels start on 64-bit boundaries, so base already points at (start_bit >> 4)
+    return src.base[(size_t)((src.r + d) & src.slot_mask) * CIFBITS + (i & 15u) * TI_SEG + (i >> 4)];
 }
 
 // packed soft values (x0 in byte 0) of trellis step tau, zero where punctured
@@ -534,45 +553,124 @@ __device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *__
     return x;
 }
 
-// one add-compare-select step.  sig/nsig: per-lane +-1 bytes of this phase's branch
-// (and their negation); xs: the step's four soft values, wave-uniform.
-// The decision (1 = the survivor came from the partner lane) is shifted into `bits`.
+// ---- one add-compare-select step, hand scheduled (6 VALU issues):
+//   S = pm - M, K = pm + M (M = dot4 of the +-1 branch signs with the four soft values),
+//   recv = S of the butterfly partner lane, pm' = max(K, recv); the decision recv > K is the
+//   sign of K - pm'.  gfx950 needs 3 wait states between a DOT write and another VALU's
+//   read of that register (and 2 before a DPP read), so the gap between the dot4 pair and
+//   the DPP max is filled with useful work: the next step's v_readlane and the PREVIOUS
+//   step's decision (Kp - pm, shifted into `bits`).  A run therefore starts with Kp = pm
+//   (a dummy 0 decision that is later shifted out) and ends with acs_flush().
+//   (v_subrev_u32_dpp is not usable for K - recv: measured on gfx950 it swizzles the
+//   minuend, like v_sub_u32_dpp.)
+#define DABX_ACS_DPP(CTRL)                                                                        \
+    asm volatile("v_dot4_i32_i8 %[S], %[nsig], %[xs], %[pm]\n\t"                                  \
+                 "v_dot4_i32_i8 %[K], %[sig], %[xs], %[pm]\n\t"                                   \
+                 "v_readlane_b32 %[xn], %[xv], %[idx]\n\t"                                        \
+                 "v_sub_u32 %[D], %[Kp], %[pm]\n\t"                                               \
+                 "v_alignbit_b32 %[bits], %[bits], %[D], 31\n\t"                                  \
+                 "v_max_i32_dpp %[pm], %[S], %[K] " CTRL " row_mask:0xf bank_mask:0xf"            \
+                 : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D), [xn] "=&s"(xn) \
+                 : [sig] "v"(sig), [nsig] "v"(nsig), [xs] "s"(xs), [xv] "v"(xv), [idx] "s"(idx), [Kp] "v"(Kp))
+
+#define DABX_ACS_LDS(EXCH, ...)                                                                   \
+    asm volatile("v_dot4_i32_i8 %[S], %[nsig], %[xs], %[pm]\n\t"                                  \
+                 "v_dot4_i32_i8 %[K], %[sig], %[xs], %[pm]\n\t"                                   \
+                 "v_readlane_b32 %[xn], %[xv], %[idx]\n\t"                                        \
+                 "v_sub_u32 %[D], %[Kp], %[pm]\n\t"                                               \
+                 "v_alignbit_b32 %[bits], %[bits], %[D], 31\n\t"                                  \
+                 EXCH "\n\t"                                                                      \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                       \
+                 "v_max_i32 %[pm], %[K], %[D]"                                                    \
+                 : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D), [xn] "=&s"(xn) \
+                 : [sig] "v"(sig), [nsig] "v"(nsig), [xs] "s"(xs), [xv] "v"(xv), [idx] "s"(idx), [Kp] "v"(Kp), [ad] "v"(lane_x32) __VA_ARGS__)
+
 template <int PH>
-__device__ __forceinline__ void acs(int &pm, int sig, int nsig, int xs, int lane, uint32_t &bits)
+__device__ __forceinline__ int acs(int &pm, int &Kp, int sig, int nsig, int xs, int xv, int idx, int lane_x32, uint32_t &bits)
 {
-    int keep = __builtin_amdgcn_sdot4(sig, xs, pm, false);
-    int send = __builtin_amdgcn_sdot4(nsig, xs, pm, false);
-    int recv = exchange<PH>(send, lane);
-    bits = __builtin_amdgcn_alignbit(bits, (uint32_t)(keep - recv), 31);      // sign bit: recv > keep
-    pm = max(keep, recv);
+    int S, K, D, xn;
+    if (PH == 0) DABX_ACS_DPP("quad_perm:[1,0,3,2]");
+    else if (PH == 1) DABX_ACS_DPP("quad_perm:[2,3,0,1]");
+    else if (PH == 2) DABX_ACS_DPP("row_half_mirror");
+    else if (PH == 3) DABX_ACS_DPP("row_ror:8");
+    else if (PH == 4) DABX_ACS_LDS("ds_swizzle_b32 %[D], %[S] offset:swizzle(SWAP,16)");
+    else DABX_ACS_LDS("ds_bpermute_b32 %[D], %[ad], %[S]");
+    Kp = K;
+    return xn;
 }
 
+// decision of the last step of a run
+__device__ __forceinline__ void acs_flush(int pm, int Kp, uint32_t &bits)
+{
+    int D;
+    asm volatile("v_sub_u32 %[D], %[Kp], %[pm]\n\t"
+                 "v_alignbit_b32 %[bits], %[bits], %[D], 31"
+                 : [bits] "+v"(bits), [D] "=&v"(D) : [Kp] "v"(Kp), [pm] "v"(pm));
+}
+
+// cnt (1..32) steps starting at lane s0 of xv, the first one in phase PH0
 template <int PH0>
-__device__ __forceinline__ void acs_run(int &pm, const int *sig, const int *nsig, int xcur, int s0, int cnt, int lane,
+__device__ __forceinline__ void acs_run(int &pm, const int *sig, const int *nsig, int xv, int s0, int cnt, int lane_x32,
                                         uint32_t &bits)
 {
-    // PH0 = phase of step s0; full groups of six, then the remainder
+    int xs, Kp;
+    // first soft-value word of the run; Kp = pm makes the first (dummy) decision 0.
+    // The nop covers the VALU-writes-SGPR -> VALU-reads hazard of xs.
+    asm volatile("v_readlane_b32 %0, %2, %3\n\tv_mov_b32 %1, %4\n\ts_nop 1" : "=s"(xs), "=&v"(Kp) : "v"(xv), "s"(s0), "v"(pm));
     int s = 0;
+#define DABX_STEP(J) xs = acs<(PH0 + J) % 6>(pm, Kp, sig[(PH0 + J) % 6], nsig[(PH0 + J) % 6], xs, xv, s0 + s + J + 1, lane_x32, bits)
     for (; s + 6 <= cnt; s += 6) {
-        acs<(PH0 + 0) % 6>(pm, sig[(PH0 + 0) % 6], nsig[(PH0 + 0) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 0), lane, bits);
-        acs<(PH0 + 1) % 6>(pm, sig[(PH0 + 1) % 6], nsig[(PH0 + 1) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 1), lane, bits);
-        acs<(PH0 + 2) % 6>(pm, sig[(PH0 + 2) % 6], nsig[(PH0 + 2) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 2), lane, bits);
-        acs<(PH0 + 3) % 6>(pm, sig[(PH0 + 3) % 6], nsig[(PH0 + 3) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 3), lane, bits);
-        acs<(PH0 + 4) % 6>(pm, sig[(PH0 + 4) % 6], nsig[(PH0 + 4) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 4), lane, bits);
-        acs<(PH0 + 5) % 6>(pm, sig[(PH0 + 5) % 6], nsig[(PH0 + 5) % 6], __builtin_amdgcn_readlane(xcur, s0 + s + 5), lane, bits);
+        DABX_STEP(0); DABX_STEP(1); DABX_STEP(2); DABX_STEP(3); DABX_STEP(4); DABX_STEP(5);
     }
-    if (s < cnt) { acs<(PH0 + 0) % 6>(pm, sig[(PH0 + 0) % 6], nsig[(PH0 + 0) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
-    if (s < cnt) { acs<(PH0 + 1) % 6>(pm, sig[(PH0 + 1) % 6], nsig[(PH0 + 1) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
-    if (s < cnt) { acs<(PH0 + 2) % 6>(pm, sig[(PH0 + 2) % 6], nsig[(PH0 + 2) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
-    if (s < cnt) { acs<(PH0 + 3) % 6>(pm, sig[(PH0 + 3) % 6], nsig[(PH0 + 3) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
-    if (s < cnt) { acs<(PH0 + 4) % 6>(pm, sig[(PH0 + 4) % 6], nsig[(PH0 + 4) % 6], __builtin_amdgcn_readlane(xcur, s0 + s), lane, bits); ++s; }
+    const int rem = cnt - s;                       // 0..5 steps left, statically phased
+    if (rem > 0) DABX_STEP(0);
+    if (rem > 1) DABX_STEP(1);
+    if (rem > 2) DABX_STEP(2);
+    if (rem > 3) DABX_STEP(3);
+    if (rem > 4) DABX_STEP(4);
+#undef DABX_STEP
+    acs_flush(pm, Kp, bits);
+}
+
+// Traceback of the 96 steps [96 g, 96 g + 96) on the scalar unit.  A = survivor position in
+// basis coordinates after step 96 g + 95.  Inside six steps of phases 5..0 every bit of A is
+// read (it is that step's decoded bit) before it is toggled, so A at the top of a group IS
+// the six decoded bits of the group: bit q = step 6 grp + q.
+__device__ __forceinline__ uint32_t traceback96(const uint32_t *dec, int g, int lane, uint32_t A,
+                                                const uint32_t *__restrict__ prbs32, uint32_t *out32)
+{
+    uint32_t w[3], o[3] = {0u, 0u, 0u};                  // o[k]: step 32 k + j at bit 31 - j
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] = dec[(3 * g + k) * 64 + lane];
+#pragma unroll
+    for (int grp = 15; grp >= 0; --grp) {
+        const uint32_t rev = __builtin_bitreverse32(A) >> 26;        // step 6 grp + q at bit 5 - q
+        const int f = 6 * grp, k = f >> 5, off = f & 31;
+        if (off + 6 <= 32) o[k] |= rev << (26 - off);
+        else {
+            const int n1 = off + 6 - 32;                              // bits that spill into the next word
+            o[k] |= rev >> n1;
+            o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
+        }
+#pragma unroll
+        for (int q = 5; q >= 0; --q) {
+            const int t = f + q, pos = 31 - (t & 31);
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)w[t >> 5], (int)A);
+            A ^= ((pos >= q) ? (x >> (pos - q)) : (x << (q - pos))) & (1u << q);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out32[3 * g + k] = __builtin_bswap32(o[k] ^ prbs32[3 * g + k]);
+    }
+    return A;
 }
 
 // Decode one terminated codeword with the calling wave.
 //   dec:    32-bit decision words [half-block of 32 steps][64]: the word of the lane
 //           with basis coordinates A is stored at index A, bit 31-j = step j
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
-//   out:    n_in/8 bytes
+//   out:    n_in/8 bytes.  nsteps, n_in and all pointers are wave-uniform.
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out)
 {
@@ -593,6 +691,7 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         sig[ph] = sg; nsig[ph] = ng;
     }
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
+    const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
     int pm = lane == 0 ? 0 : PM_INIT;
     const int nhb = (nsteps + 31) >> 5;                          // half-blocks of 32 steps
     int xnext = gather_step(src, info, lane, nsteps);
@@ -606,15 +705,18 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         const int s0 = (hb & 1) * 32;
         uint32_t bits = 0;
         switch (hb % 3) {                                        // (32 hb) mod 6 = 2 (hb mod 3)
-        case 0: acs_run<0>(pm, sig, nsig, xcur, s0, cnt, lane, bits); break;
-        case 1: acs_run<2>(pm, sig, nsig, xcur, s0, cnt, lane, bits); break;
-        default: acs_run<4>(pm, sig, nsig, xcur, s0, cnt, lane, bits); break;
+        case 0: acs_run<0>(pm, sig, nsig, xcur, s0, cnt, lane_x32, bits); break;
+        case 1: acs_run<2>(pm, sig, nsig, xcur, s0, cnt, lane_x32, bits); break;
+        default: acs_run<4>(pm, sig, nsig, xcur, s0, cnt, lane_x32, bits); break;
         }
         dec[hb * 64 + coordA] = bits << (32 - cnt);              // cnt >= 1
     }
-    // ---- traceback on the scalar unit, in basis coordinates, from state 0
+    // ---- traceback on the scalar unit, in basis coordinates, from state 0.
+    // The top (nsteps mod 96) steps go through the generic loop, the rest in 96-step blocks.
     uint32_t A = 0;
-    for (int hb = nhb - 1; hb >= 0; --hb) {
+    const int nfast = nsteps / 96;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    for (int hb = nhb - 1; hb >= 3 * nfast; --hb) {
         const uint32_t word = dec[hb * 64 + lane];
         const int cnt = min(32, nsteps - hb * 32);
         uint32_t ph = (uint32_t)(hb * 32 + cnt - 1) % 6u;
@@ -626,9 +728,9 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
             A ^= d << ph;
             ph = ph == 0 ? 5u : ph - 1u;
         }
-        const int nb = n_in - hb * 32;                           // n_in is a multiple of 32
-        if (nb > 0 && lane == 0) reinterpret_cast<uint32_t *>(out)[hb] = __builtin_bswap32(o ^ prbs32[hb]);
+        if (n_in - hb * 32 > 0 && lane == 0) out32[hb] = __builtin_bswap32(o ^ prbs32[hb]);   // n_in is a multiple of 32
     }
+    for (int g = nfast - 1; g >= 0; --g) A = traceback96(dec, g, lane, A, prbs32, out32);
 }
 
 }  // namespace
@@ -639,7 +741,7 @@ template <bool LDS_DEC>
 __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__restrict__ work, int n_work, int lds_words)
 {
     extern __shared__ uint32_t dec_lds[];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
     const DevWork w = work[wi];
@@ -654,7 +756,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
         const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
         const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
         if (r < 0 || st.acq_fail) return;            // time de-interleaver still filling (k_finish flags it)
-        VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + sc.start_bit, r, C.ti_slots - 1};
+        VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + (sc.start_bit >> 4), r, C.ti_slots - 1};
         uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
         viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out);
     }
@@ -664,7 +766,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
 __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int n_coded, const uint32_t *info, int nsteps,
                                                         int n_in, const uint32_t *prbs, uint32_t *scratch, uint8_t *out, int n_cw)
 {
-    const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wi >= n_cw) return;
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps + 31) >> 5) * 64), out + (size_t)wi * (n_in / 8));
