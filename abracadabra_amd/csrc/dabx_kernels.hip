@@ -541,11 +541,15 @@ __device__ __forceinline__ int8_t soft_at(const VitSrc &src, uint32_t i)
     return src.base[(size_t)((src.r + d) & src.slot_mask) * CIFBITS + (i & 15u) * TI_SEG + (i >> 4)];
 }
 
-// packed soft values (x0 in byte 0) of trellis step tau, zero where punctured
-__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *__restrict__ info, int tau, int nsteps)
+// depuncturing word of trellis step tau (0 = past the end: nothing to fetch)
+__device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info, int tau, int nsteps)
 {
-    if (tau >= nsteps) return 0;
-    uint32_t w = info[tau], off = w >> 4;
+    return tau < nsteps ? info[tau] : 0u;
+}
+// packed soft values (x0 in byte 0) of the step described by w, zero where punctured
+__device__ __forceinline__ int gather_step(const VitSrc &src, uint32_t w)
+{
+    uint32_t off = w >> 4;
     int x = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -632,6 +636,26 @@ __device__ __forceinline__ void acs_run(int &pm, const int *sig, const int *nsig
     acs_flush(pm, Kp, bits);
 }
 
+// 32 consecutive steps in ONE asm statement (text generated by tools/gen_acs32.py): no
+// compiler-inserted pads between steps, immediate v_readlane indices (soft values of the 32
+// steps sit in lanes 0..31 of xv).  bits must be 0 on entry and holds the 32 decisions on exit.
+#include "dabx_acs32.inc"
+template <int PH0>
+__device__ __forceinline__ void acs32(int &pm, const int *sig, const int *nsig, int xv, int lane_x32, uint32_t &bits)
+{
+    int S, Ka, Kb, D, xa, xb;
+#define DABX_ACS32_OPS                                                                                              \
+    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [Ka] "=&v"(Ka), [Kb] "=&v"(Kb), [D] "=&v"(D), [xa] "=&s"(xa), \
+      [xb] "=&s"(xb)                                                                                                \
+    : [xv] "v"(xv), [ad] "v"(lane_x32), [s0] "v"(sig[0]), [s1] "v"(sig[1]), [s2] "v"(sig[2]), [s3] "v"(sig[3]),     \
+      [s4] "v"(sig[4]), [s5] "v"(sig[5]), [n0] "v"(nsig[0]), [n1] "v"(nsig[1]), [n2] "v"(nsig[2]), [n3] "v"(nsig[3]), \
+      [n4] "v"(nsig[4]), [n5] "v"(nsig[5])
+    if (PH0 == 0) asm volatile(DABX_ACS32_TEXT_0 DABX_ACS32_OPS);
+    else if (PH0 == 2) asm volatile(DABX_ACS32_TEXT_2 DABX_ACS32_OPS);
+    else asm volatile(DABX_ACS32_TEXT_4 DABX_ACS32_OPS);
+#undef DABX_ACS32_OPS
+}
+
 // Traceback of the 96 steps [96 g, 96 g + 96) on the scalar unit.  A = survivor position in
 // basis coordinates after step 96 g + 95.  Inside six steps of phases 5..0 every bit of A is
 // read (it is that step's decoded bit) before it is toggled, so A at the top of a group IS
@@ -694,22 +718,39 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
     int pm = lane == 0 ? 0 : PM_INIT;
     const int nhb = (nsteps + 31) >> 5;                          // half-blocks of 32 steps
-    int xnext = gather_step(src, info, lane, nsteps);
-    int xcur = 0;
-    for (int hb = 0; hb < nhb; ++hb) {
-        if ((hb & 1) == 0) {
-            xcur = xnext;
-            xnext = gather_step(src, info, (hb + 2) * 32 + lane, nsteps);
+    // Soft-bit pipeline, three blocks of 64 steps deep: the depuncturing words of block b+2 and
+    // the soft bytes of block b+1 are in flight while block b runs, so each of the two
+    // dependent loads has a whole block of ACS work to hide behind.
+    int xnext = gather_step(src, step_word(info, lane, nsteps));
+    uint32_t wnext = step_word(info, 64 + lane, nsteps);
+    const int nblk = (nsteps + 63) >> 6;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int xcur = xnext;
+        xnext = gather_step(src, wnext);
+        wnext = step_word(info, (blk + 2) * 64 + lane, nsteps);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int hb = 2 * blk + half;
+            const int cnt = min(32, nsteps - hb * 32);
+            if (cnt <= 0) break;
+            uint32_t bits = 0;
+            // second half: bring lanes 32..63 of the gathered soft values down to lanes 0..31
+            const int xv = half ? __builtin_amdgcn_ds_bpermute(lane_x32, xcur) : xcur;
+            if (cnt == 32) {
+                switch (hb % 3) {                                // (32 hb) mod 6 = 2 (hb mod 3)
+                case 0: acs32<0>(pm, sig, nsig, xv, lane_x32, bits); break;
+                case 1: acs32<2>(pm, sig, nsig, xv, lane_x32, bits); break;
+                default: acs32<4>(pm, sig, nsig, xv, lane_x32, bits); break;
+                }
+            } else {                                             // the 6 tail steps
+                switch (hb % 3) {
+                case 0: acs_run<0>(pm, sig, nsig, xv, 0, cnt, lane_x32, bits); break;
+                case 1: acs_run<2>(pm, sig, nsig, xv, 0, cnt, lane_x32, bits); break;
+                default: acs_run<4>(pm, sig, nsig, xv, 0, cnt, lane_x32, bits); break;
+                }
+            }
+            dec[hb * 64 + coordA] = bits << (32 - cnt);          // cnt >= 1
         }
-        const int cnt = min(32, nsteps - hb * 32);
-        const int s0 = (hb & 1) * 32;
-        uint32_t bits = 0;
-        switch (hb % 3) {                                        // (32 hb) mod 6 = 2 (hb mod 3)
-        case 0: acs_run<0>(pm, sig, nsig, xcur, s0, cnt, lane_x32, bits); break;
-        case 1: acs_run<2>(pm, sig, nsig, xcur, s0, cnt, lane_x32, bits); break;
-        default: acs_run<4>(pm, sig, nsig, xcur, s0, cnt, lane_x32, bits); break;
-        }
-        dec[hb * 64 + coordA] = bits << (32 - cnt);              // cnt >= 1
     }
     // ---- traceback on the scalar unit, in basis coordinates, from state 0.
     // The top (nsteps mod 96) steps go through the generic loop, the rest in 96-step blocks.

@@ -44,7 +44,7 @@ class StreamState(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libdabsdr_amd.so")
+    return os.environ.get("DABX_LIBRARY", os.path.join(_HERE, "libdabsdr_amd.so"))
 
 
 def build_library():
