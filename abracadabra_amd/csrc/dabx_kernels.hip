@@ -76,10 +76,11 @@ __device__ __forceinline__ void r8(cf v[8])
     v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
 }
 
-// LDS index with one pad slot per 32 complex values (keeps the stride-32 and
-// stride-4 passes off a single bank)
-__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
-constexpr int FFT_LDS = 2048 + 64;
+// LDS index with four pad slots (32 bytes) per 32 complex values: rows of the stride-4 pass
+// then start 8 banks apart, so a 32-lane ds_read_b64 group (8 rows x 4 values) covers all
+// 64 banks once
+__device__ __forceinline__ int pad(int i) { return i + ((i >> 5) << 2); }
+constexpr int FFT_LDS = 2048 + 256;
 
 struct Twiddles { cf a[7], b[7], c[7]; };          // per-thread constants of passes A, B, C
 
