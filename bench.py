@@ -63,6 +63,24 @@ def make_stream(args, rank, s, sub):
     return iq, fib, msc, shift
 
 
+def measured_traffic(S, F, kernel="k_viterbi"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py from the same bench
+    command under rocprofv3); None when no profile matches this workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    for f in reversed(files):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == {"streams": S, "frames_per_step": F}:
+            for k, v in t["kernels"].items():
+                if kernel in k:
+                    return v["hbm_bytes_per_launch"], os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(args, sub):
     """Oracle (scalar CPU port of the same chain) timed on one host core over a bounded sample."""
     from oracle import binding as ob
@@ -162,6 +180,7 @@ def main():
         vit_ms = phase_ms[2] / args.steps
         achieved = S * F * BYTES_VITERBI / (vit_ms * 1e-3) / 1e9
         acs_rate = S * F * (4 * 774 + 4 * args.nsub * 1542) * 64 / (vit_ms * 1e-3)
+        traffic, traffic_src = measured_traffic(S, F) if args.nsub == 18 else (None, None)
         out = {
             "metric": "DAB Mode-I ensembles decoded x real-time per GPU (2048-FFT + de-interleave + Viterbi, full FIC+MSC)",
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,7 +196,8 @@ def main():
                                    "viterbi": round(vit_ms, 3), "crc_state": round(phase_ms[3] / args.steps, 3),
                                    "all": round(phase_ms[4] / args.steps, 3)},
             "roofline": {"kernel": "k_viterbi", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": S * F * BYTES_VITERBI,
                          "note": "VALU/DPP-bound kernel: HBM fraction is small by construction (SURVEY.md §0.8)",
                          "acs_per_s": round(acs_rate, 0),
                          "chain_algorithmic_GBps": round(value / world / FRAME_S * BYTES_CHAIN / 1e9, 2)},
