@@ -95,7 +95,7 @@ int protection_enum(const figdb::SubChannel &sc)
 {
     // numbering of the reference's DabProtectionLevel (src/dabtables.h:35-55):
     // UEP 1..5 = 1..5, EEP 1-A..4-A = 6..9, EEP 1-B..4-B = 10..13
-    if (!sc.long_form) return 0;
+    if (!sc.long_form) return sc.level;             // UEP 1..5
     return (sc.option == 0 ? 5 : 9) + sc.level;
 }
 
@@ -130,6 +130,7 @@ int get_component_item(dabsdrHandle_t h, uint8_t idx, dabsdrServiceCompListItem_
         out->SubChAddr = static_cast<int16_t>(sc.start);
         out->SubChSize = static_cast<uint16_t>(sc.size);
         out->protectionLevel = static_cast<uint8_t>(protection_enum(sc));
+        if (!sc.long_form) out->uepIdx = static_cast<uint8_t>(sc.uep_index);
         if (c.tmid == 0) { out->streamAudio.ASCTy = static_cast<uint8_t>(c.ascty_dscty); out->streamAudio.bitRate = static_cast<uint16_t>(sc.kbps); }
         else { out->streamData.DSCTy = static_cast<uint8_t>(c.ascty_dscty); out->streamData.bitRate = static_cast<uint16_t>(sc.kbps); }
     } else if (c.tmid == 3) {
@@ -233,8 +234,8 @@ void handle_request(dabsdr_s *h, const Request &r)
                 if (c.scids != r.b) continue;
                 auto it = h->db.subch.find(c.subch);
                 if (c.tmid == 3 || it == h->db.subch.end()) { st = DABSDR_NSTAT_SERVICE_NOT_READY; break; }
-                if (!it->second.long_form) { st = DABSDR_NSTAT_SERVICE_NOT_SUPPORTED; break; }   // UEP: next round
                 dabx_subch_t sc = {it->second.start, it->second.option, it->second.level, it->second.kbps};
+                if (!it->second.long_form) sc = {it->second.start, 2, it->second.uep_index, 0};   // UEP short form
                 st = dabx_set_subchannels(h->ctx, 0, 1, &sc) >= 0 ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_SERVICE_NOT_SUPPORTED;
                 if (st == DABSDR_NSTAT_SUCCESS) { h->sel_sid = r.a; h->sel_scids = r.b; h->sel_active = true; }
                 break;

@@ -292,7 +292,7 @@ int dabx_set_subchannels(dabx_ctx *c, int s, int n, const dabx_subch_t *sub)
     std::vector<DevSub> ds(64, DevSub{});
     int out_off = 0;
     for (int i = 0; i < n; ++i) {
-        if (!dabx::eep_profile(sub[i].option, sub[i].level, sub[i].kbps, prof[i])) return DABX_E_PROFILE;
+        if (!dabx::any_profile(sub[i].option, sub[i].level, sub[i].kbps, prof[i])) return DABX_E_PROFILE;
         if (sub[i].start_cu < 0 || sub[i].start_cu + prof[i].n_cu > dabx::kNumCu) return DABX_E_ARG;
         ds[i] = {sub[i].start_cu * dabx::kCuBits, prof[i].steps(), prof[i].n_in, c->pool_lookup(prof[i]), out_off};
         out_off += prof[i].n_in / 8;
@@ -528,7 +528,7 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     if (!c || !soft || !out || n_cw < 1) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     dabx::Profile p = dabx::fic_profile();
-    if (kind != 0 && !dabx::eep_profile(option, level, kbps, p)) return DABX_E_PROFILE;
+    if (kind != 0 && !dabx::any_profile(option, level, kbps, p)) return DABX_E_PROFILE;
     const auto info = dabx::step_info(p);
     const int nsteps = p.steps();
     const size_t words = static_cast<size_t>(((nsteps + 31) >> 5) * 64);

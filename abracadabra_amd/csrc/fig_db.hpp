@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include "dabx_spec.hpp"
+
 namespace figdb {
 
 struct SubChannel {
@@ -125,6 +127,8 @@ private:
                     p += 4; n -= 4;
                 } else {
                     s.uep_index = p[2] & 0x3F;
+                    dabx::Profile prof;
+                    if (dabx::uep_profile(s.uep_index, prof, &s.kbps)) { s.size = prof.n_cu; s.level = dabx::uep_rows()[s.uep_index][1]; }
                     p += 3; n -= 3;
                 }
                 subch[s.id] = s;

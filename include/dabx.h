@@ -41,7 +41,7 @@ enum {
     DABX_E_NOMEM = -3,
     DABX_E_UNDERRUN = -4,   /* a stream does not hold enough samples for the request */
     DABX_E_OVERRUN = -5,    /* push would overwrite samples not yet consumed         */
-    DABX_E_PROFILE = -6,    /* unsupported protection profile                        */
+    DABX_E_PROFILE = -6,    /* protection profile not in EN 300 401 §11.3            */
 };
 
 /* sample formats of the reference's raw-file input
@@ -77,8 +77,9 @@ typedef struct {
     int64_t wr;                   /* samples pushed so far (host side)                    */
 } dabx_stream_state_t;
 
-/* one sub-channel of the MSC: EEP protection only in this version
- * (ETSI EN 300 401 §11.3.2); option 0 = set A, 1 = set B; level 1..4 */
+/* one sub-channel of the MSC, as FIG 0/1 announces it (ETSI EN 300 401 §6.2.1, §11.3):
+ *   option 0 / 1: EEP set A / B, level 1..4, kbps = bit rate          (long form)
+ *   option 2:     UEP, level = the 6-bit table index 0..63, kbps unused (short form) */
 typedef struct {
     int32_t start_cu;
     int32_t option;

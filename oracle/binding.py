@@ -73,6 +73,16 @@ def eep_profile(option, level, kbps):
     return p
 
 
+def any_profile(option, level, kbps=0):
+    """option 0/1: EEP set A/B (level 1..4, kbps); option 2: UEP with level = table index 0..63"""
+    p = Profile()
+    L = lib()
+    L.dab_profile_any.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    if L.dab_profile_any(option, level, kbps, C.byref(p)):
+        raise ValueError("invalid protection profile")
+    return p
+
+
 def subch_layout(n=18, kbps=64, option=0, level=3):
     """n equal sub-channels packed from CU 0: [[start_cu, option, level, kbps], …]"""
     size = eep_profile(option, level, kbps).n_cu

@@ -263,7 +263,7 @@ int orx_set_subch(orx_t *s, int n, const int32_t *cfg)
     for (int i = 0; i < n; i++) {
         subch_t *u = &s->sub[i];
         u->start_cu = cfg[4 * i]; u->option = cfg[4 * i + 1]; u->level = cfg[4 * i + 2]; u->kbps = cfg[4 * i + 3];
-        if (dab_profile_eep(u->option, u->level, u->kbps, &u->prof)) return -2;
+        if (dab_profile_any(u->option, u->level, u->kbps, &u->prof)) return -2;
         if (u->start_cu < 0 || u->start_cu + u->prof.n_cu > DAB_NCU) return -3;
         u->stepinfo = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(u->prof.n_in + 8));
         u->nsteps = dab_profile_stepinfo(&u->prof, u->stepinfo);
@@ -538,7 +538,7 @@ int orx_decode_linear(int kind, int option, int level, int kbps, const int8_t *s
 {
     tables_init();
     dab_profile_t p;
-    if (kind == 0) dab_profile_fic(&p); else if (dab_profile_eep(option, level, kbps, &p)) return -1;
+    if (kind == 0) dab_profile_fic(&p); else if (dab_profile_any(option, level, kbps, &p)) return -1;
     uint32_t *info = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(p.n_in + 8));
     int ns = dab_profile_stepinfo(&p, info);
     lin_ctx c = {soft};

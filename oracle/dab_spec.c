@@ -165,6 +165,99 @@ int dab_profile_eep(int option, int level, int kbps, dab_profile_t *p)
     return 0;
 }
 
+/* EN 300 401 §11.3.1 tables 31-33: unequal error protection, indexed by the 6-bit table
+ * index of FIG 0/1's short form (table 8).  Columns: bit rate, protection level, L1..L4,
+ * PI1..PI4, padding bits.  Every row satisfies sum(L)*32 = 24*bitrate and
+ * sum(L*4*(8+PI)) + 12 + padding = 64 * sub-channel size (tests/test_oracle_spec.py). */
+static const int16_t uep_table[64][11] = {
+    {32, 5, 3, 4, 17, 0, 5, 3, 2, 0, 0},
+    {32, 4, 3, 3, 18, 0, 11, 6, 5, 0, 0},
+    {32, 3, 3, 4, 14, 3, 15, 9, 6, 8, 0},
+    {32, 2, 3, 4, 14, 3, 22, 13, 8, 13, 0},
+    {32, 1, 3, 5, 13, 3, 24, 17, 12, 17, 4},
+    {48, 5, 4, 3, 26, 3, 5, 4, 2, 3, 0},
+    {48, 4, 3, 4, 26, 3, 9, 6, 4, 6, 0},
+    {48, 3, 3, 4, 26, 3, 15, 10, 6, 9, 4},
+    {48, 2, 3, 4, 26, 3, 24, 14, 8, 15, 0},
+    {48, 1, 3, 5, 25, 3, 24, 18, 13, 18, 0},
+    {56, 5, 6, 10, 23, 3, 5, 4, 2, 3, 0},
+    {56, 4, 6, 10, 23, 3, 9, 6, 4, 5, 0},
+    {56, 3, 6, 12, 21, 3, 16, 7, 6, 9, 0},
+    {56, 2, 6, 10, 23, 3, 23, 13, 8, 13, 8},
+    {64, 5, 6, 9, 31, 2, 5, 3, 2, 3, 0},
+    {64, 4, 6, 9, 33, 0, 11, 6, 5, 0, 0},
+    {64, 3, 6, 12, 27, 3, 16, 8, 6, 9, 0},
+    {64, 2, 6, 10, 29, 3, 23, 13, 8, 13, 8},
+    {64, 1, 6, 11, 28, 3, 24, 18, 12, 18, 4},
+    {80, 5, 6, 10, 41, 3, 6, 3, 2, 3, 0},
+    {80, 4, 6, 10, 41, 3, 11, 6, 5, 6, 0},
+    {80, 3, 6, 11, 40, 3, 16, 8, 6, 7, 0},
+    {80, 2, 6, 10, 41, 3, 23, 13, 8, 13, 8},
+    {80, 1, 6, 10, 41, 3, 24, 17, 12, 18, 4},
+    {96, 5, 7, 9, 53, 3, 5, 4, 2, 4, 0},
+    {96, 4, 7, 10, 52, 3, 9, 6, 4, 6, 0},
+    {96, 3, 6, 12, 51, 3, 16, 9, 6, 10, 4},
+    {96, 2, 6, 10, 53, 3, 22, 12, 9, 12, 0},
+    {96, 1, 6, 13, 50, 3, 24, 18, 13, 19, 0},
+    {112, 5, 14, 17, 50, 3, 5, 4, 2, 5, 0},
+    {112, 4, 11, 21, 49, 3, 9, 6, 4, 8, 0},
+    {112, 3, 11, 23, 47, 3, 16, 8, 6, 9, 0},
+    {112, 2, 11, 21, 49, 3, 23, 12, 9, 14, 4},
+    {128, 5, 12, 19, 62, 3, 5, 3, 2, 4, 0},
+    {128, 4, 11, 21, 61, 3, 11, 6, 5, 7, 0},
+    {128, 3, 11, 22, 60, 3, 16, 9, 6, 10, 4},
+    {128, 2, 11, 21, 61, 3, 22, 12, 9, 14, 0},
+    {128, 1, 11, 20, 62, 3, 24, 17, 13, 19, 8},
+    {160, 5, 11, 19, 87, 3, 5, 4, 2, 4, 0},
+    {160, 4, 11, 23, 83, 3, 11, 6, 5, 9, 0},
+    {160, 3, 11, 24, 82, 3, 16, 8, 6, 11, 0},
+    {160, 2, 11, 21, 85, 3, 22, 11, 9, 13, 0},
+    {160, 1, 11, 22, 84, 3, 24, 18, 12, 19, 0},
+    {192, 5, 11, 20, 110, 3, 6, 4, 2, 5, 0},
+    {192, 4, 11, 22, 108, 3, 10, 6, 4, 9, 0},
+    {192, 3, 11, 24, 106, 3, 16, 10, 6, 11, 0},
+    {192, 2, 11, 20, 110, 3, 22, 13, 9, 13, 8},
+    {192, 1, 11, 21, 109, 3, 24, 20, 13, 24, 0},
+    {224, 5, 12, 22, 131, 3, 8, 6, 2, 6, 4},
+    {224, 4, 12, 26, 127, 3, 12, 8, 4, 11, 0},
+    {224, 3, 11, 20, 134, 3, 16, 10, 7, 9, 0},
+    {224, 2, 11, 22, 132, 3, 24, 16, 10, 15, 0},
+    {224, 1, 11, 24, 130, 3, 24, 20, 12, 20, 4},
+    {256, 5, 11, 24, 154, 3, 6, 5, 2, 5, 0},
+    {256, 4, 11, 24, 154, 3, 12, 9, 5, 10, 4},
+    {256, 3, 11, 27, 151, 3, 16, 10, 7, 10, 0},
+    {256, 2, 11, 22, 156, 3, 24, 14, 10, 13, 8},
+    {256, 1, 11, 26, 152, 3, 24, 19, 14, 18, 4},
+    {320, 5, 11, 26, 200, 3, 8, 5, 2, 6, 4},
+    {320, 4, 11, 25, 201, 3, 13, 9, 5, 10, 8},
+    {320, 2, 11, 26, 200, 3, 24, 17, 9, 17, 0},
+    {384, 5, 11, 27, 247, 3, 8, 6, 2, 7, 0},
+    {384, 3, 11, 24, 250, 3, 16, 9, 7, 10, 4},
+    {384, 1, 12, 28, 245, 3, 24, 20, 14, 23, 8}
+};
+
+int dab_profile_uep(int index, dab_profile_t *p, int *kbps, int *level)
+{
+    memset(p, 0, sizeof *p);
+    if (index < 0 || index > 63) return -1;
+    const int16_t *r = uep_table[index];
+    p->nseg = r[5] ? 4 : 3;
+    int coded = 12 + r[10], blocks = 0;
+    for (int s = 0; s < p->nseg; s++) { p->L[s] = r[2 + s]; p->PI[s] = r[6 + s]; blocks += p->L[s]; coded += p->L[s] * 4 * (8 + p->PI[s]); }
+    p->n_in = 32 * blocks;
+    p->n_coded = coded;                 /* includes the padding bits, which carry no information */
+    p->n_cu = coded / DAB_CU_BITS;
+    if (kbps) *kbps = r[0];
+    if (level) *level = r[1];
+    return (coded % DAB_CU_BITS) ? -1 : 0;
+}
+
+int dab_profile_any(int option, int level, int kbps, dab_profile_t *p)
+{
+    if (option == 2) return dab_profile_uep(level, p, NULL, NULL);
+    return dab_profile_eep(option, level, kbps, p);
+}
+
 int dab_profile_stepinfo(const dab_profile_t *p, uint32_t *info)
 {
     uint8_t v[32];

@@ -94,6 +94,11 @@ void dab_profile_fic(dab_profile_t *p);
  * (multiple of 32); level 1..4.  Returns 0 on success. */
 int dab_profile_eep(int option, int level, int bitrate_kbps, dab_profile_t *p);
 
+/* §11.3.1 UEP: index = 6-bit table index of FIG 0/1 short form (0..63) */
+int dab_profile_uep(int index, dab_profile_t *p, int *kbps, int *level);
+/* option 0/1 = EEP set A/B (level 1..4, kbps); option 2 = UEP with level = table index */
+int dab_profile_any(int option, int level, int kbps, dab_profile_t *p);
+
 /* puncture / depuncture map: for every trellis step t (0 … n_in+5) the
  * offset of its first kept bit in the punctured stream and the 4-bit keep
  * mask (bit 3 = x0).  info[t] = (offset << 4) | mask.  Returns step count. */

@@ -72,18 +72,23 @@ typedef struct { uint8_t b[30]; int len; } fig_t;
 static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *figs)
 {
     int n = 0;
-    /* FIG 0/1 sub-channel organisation, long form, up to 7 entries per FIG */
-    for (int s0 = 0; s0 < c->n_subch; s0 += 7) {
+    /* FIG 0/1 sub-channel organisation: long form (4 bytes) for EEP, short form (3 bytes,
+     * table index) for UEP; as many entries per FIG as fit into 29 data bytes */
+    for (int s = 0; s < c->n_subch;) {
         fig_t *f = &figs[n++];
-        int cnt = c->n_subch - s0 < 7 ? c->n_subch - s0 : 7;
-        f->b[0] = (uint8_t)(1 + 4 * cnt); f->b[1] = 0x01; f->len = 2;
-        for (int s = s0; s < s0 + cnt; s++) {
+        f->b[1] = 0x01; f->len = 2;
+        while (s < c->n_subch && f->len + (c->subch[s][1] == 2 ? 3 : 4) <= 30) {
             int addr = c->subch[s][0], size = prof[s].n_cu;
             f->b[f->len++] = (uint8_t)((s << 2) | (addr >> 8));
             f->b[f->len++] = (uint8_t)(addr & 0xFF);
-            f->b[f->len++] = (uint8_t)(0x80 | (c->subch[s][1] << 4) | ((c->subch[s][2] - 1) << 2) | (size >> 8));
-            f->b[f->len++] = (uint8_t)(size & 0xFF);
+            if (c->subch[s][1] == 2) f->b[f->len++] = (uint8_t)(c->subch[s][2] & 0x3F);
+            else {
+                f->b[f->len++] = (uint8_t)(0x80 | (c->subch[s][1] << 4) | ((c->subch[s][2] - 1) << 2) | (size >> 8));
+                f->b[f->len++] = (uint8_t)(size & 0xFF);
+            }
+            ++s;
         }
+        f->b[0] = (uint8_t)(f->len - 1);
     }
     /* FIG 0/2 basic service organisation: one DAB+ audio service per sub-channel */
     for (int s0 = 0; s0 < c->n_subch; s0 += 5) {
@@ -94,7 +99,7 @@ static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *f
             int sid = 0x1A01 + s;
             f->b[f->len++] = (uint8_t)(sid >> 8); f->b[f->len++] = (uint8_t)sid;
             f->b[f->len++] = 0x01;                           /* one component      */
-            f->b[f->len++] = 0x3F;                           /* TMId 0, ASCTy 63   */
+            f->b[f->len++] = (uint8_t)(c->subch[s][1] == 2 ? 0x00 : 0x3F);   /* TMId 0; ASCTy 0 (MP2) on UEP, 63 (DAB+) on EEP */
             f->b[f->len++] = (uint8_t)((s << 2) | 0x02);     /* SubChId, primary   */
         }
     }
@@ -167,7 +172,7 @@ int dab_tx_msc_bytes_per_cif(const dab_tx_cfg_t *c)
     int tot = 0;
     dab_profile_t p;
     for (int s = 0; s < c->n_subch; s++) {
-        if (dab_profile_eep(c->subch[s][1], c->subch[s][2], c->subch[s][3], &p)) return -1;
+        if (dab_profile_any(c->subch[s][1], c->subch[s][2], c->subch[s][3], &p)) return -1;
         tot += p.n_in / 8;
     }
     return tot;
@@ -188,7 +193,7 @@ int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *
     if (c->n_subch < 0 || c->n_subch > 64 || NF < 1) return -1;
     int msc_bytes = 0, off_bytes[64];
     for (int s = 0; s < c->n_subch; s++) {
-        if (dab_profile_eep(c->subch[s][1], c->subch[s][2], c->subch[s][3], &prof[s])) return -2;
+        if (dab_profile_any(c->subch[s][1], c->subch[s][2], c->subch[s][3], &prof[s])) return -2;
         if (c->subch[s][0] < 0 || c->subch[s][0] + prof[s].n_cu > DAB_NCU) return -3;
         off_bytes[s] = msc_bytes;
         msc_bytes += prof[s].n_in / 8;

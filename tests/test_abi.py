@@ -47,7 +47,7 @@ def test_no_gpu_means_loud_failure_not_fallback():
 
 
 def test_fig_database_reads_transmitted_fibs():
-    sub = [[0, 0, 3, 64], [48, 1, 4, 32]]
+    sub = [[0, 0, 3, 64], [48, 1, 4, 32], [100, 2, 17, 0]]
     _, fib, _ = ob.tx_generate(seed=4, eid=0x10AB, n_frames=3, subch=sub, snr_db=100.0)
     L = aa.load_library()
     L.dabsdr_amd_fig_dump.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
@@ -59,4 +59,6 @@ def test_fig_database_reads_transmitted_fibs():
     assert "eid=10AB ecc=E2 lto=2" in text and "GRAFT ENS" in text
     assert "subch id=0 start=0 size=48 opt=0 level=3 kbps=64" in text
     assert "subch id=1 start=48 size=15 opt=1 level=4 kbps=32" in text
+    assert "subch id=2 start=100 size=58 opt=0 level=2 kbps=64" in text          # UEP index 17 via the short form
     assert "service sid=1A01 label='SERVICE 00      ' ncomp=1 [tmid=0 ty=63 subch=0 ps=1]" in text
+    assert "service sid=1A03 label='SERVICE 02      ' ncomp=1 [tmid=0 ty=0 subch=2 ps=1]" in text

@@ -1,0 +1,137 @@
+"""The reference's 24-function dabsdr API driven exactly as src/radiocontrol.cpp drives it
+(init -> register callbacks -> dabsdr() -> Request_Tune -> notifications), with a raw-file
+style input callback (float(u8-128), blocking fill) — GPU only."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import abracadabra_amd as aa
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+NID = dict(SYNC_STATUS=1, TUNE=2, ENSEMBLE_INFO=3, SERVICE_LIST=4, SERVICE_COMPONENT_LIST=5, SERVICE_SELECTION=8,
+           PERIODIC=10, RESET=13)
+
+
+class Label(C.Structure):
+    _fields_ = [("str", C.c_char * 17), ("charField", C.c_uint16), ("charset", C.c_uint8)]
+
+
+class Ensemble(C.Structure):
+    _fields_ = [("frequency", C.c_uint32), ("ueid", C.c_uint32), ("LTO", C.c_int8), ("intTable", C.c_uint8),
+                ("alarm", C.c_uint8), ("label", Label)]
+
+
+class Periodic(C.Structure):
+    _fields_ = [("syncLevel", C.c_int), ("snr10", C.c_int16), ("freqOffset", C.c_int32), ("dateHoursMinutes", C.c_uint32),
+                ("secMsec", C.c_uint16), ("fibErrorCntr", C.c_uint16), ("mscCrcOkCntr", C.c_uint8), ("mscCrcErrorCntr", C.c_uint8),
+                ("audioServiceBytes", C.c_uint16), ("padBytes", C.c_uint16), ("rsUncorrectableCntr", C.c_uint16),
+                ("rsBitErrors", C.c_uint16), ("rsBytes", C.c_uint16)]
+
+
+class ServiceItem(C.Structure):
+    _fields_ = [("sid", C.c_uint32), ("label", Label), ("pty_s", C.c_uint8), ("pty_d", C.c_uint8), ("CAId", C.c_uint8)]
+
+
+class Ntf(C.Structure):
+    _fields_ = [("nid", C.c_int), ("status", C.c_int), ("len", C.c_uint16), ("pData", C.c_void_p)]
+
+
+class ServiceList(C.Structure):
+    _fields_ = [("numServices", C.c_uint8), ("getItem", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint8, C.POINTER(ServiceItem)))]
+
+
+def test_periodic_struct_is_32_bytes():
+    assert C.sizeof(Periodic) == 32          # the host asserts this length (radiocontrol.cpp:2407)
+
+
+def test_tune_lock_ensemble_and_service_list():
+    L = aa.load_library()
+    cfo = 1500.0
+    sub = [[0, 0, 3, 64], [48, 1, 4, 32]]
+    iq, fib, _ = ob.tx_generate(seed=77, eid=0x1234, n_frames=24, subch=sub, delay=5000, snr_db=25.0, cfo_hz=cfo)
+    samples = (iq.astype(np.float32) - 128.0)              # what RawFileWorker produces (rawfileinput.cpp:692)
+    pos = [0]
+    events, lock = [], threading.Lock()
+    handle = C.c_void_p()
+
+    @C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint16)
+    def get_samples(buf, n):
+        out = np.ctypeslib.as_array(buf, shape=(2 * n,))
+        take = samples[pos[0]:pos[0] + 2 * n]
+        out[:len(take)] = take
+        out[len(take):] = 0.0                               # flushed FIFO returns zeros (inputdevice.cpp:80-85)
+        pos[0] += 2 * n
+
+    @C.CFUNCTYPE(None, C.POINTER(Ntf), C.c_void_p)
+    def on_ntf(p, ctx):
+        n = p.contents
+        rec = dict(nid=n.nid, status=n.status, len=n.len)
+        if n.nid == NID["TUNE"]:
+            rec["freq"] = C.cast(n.pData, C.POINTER(C.c_uint32)).contents.value
+        elif n.nid == NID["SYNC_STATUS"]:
+            rec["level"] = C.cast(n.pData, C.POINTER(C.c_int)).contents.value
+        elif n.nid == NID["ENSEMBLE_INFO"]:
+            e = C.cast(n.pData, C.POINTER(Ensemble)).contents
+            rec.update(ueid=e.ueid, lto=e.LTO, label=e.label.str.decode(), freq=e.frequency)
+        elif n.nid == NID["PERIODIC"] and n.pData:
+            pr = C.cast(n.pData, C.POINTER(Periodic)).contents
+            rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel)
+        elif n.nid == NID["SERVICE_LIST"]:
+            sl = C.cast(n.pData, C.POINTER(ServiceList)).contents
+            items = []
+            for i in range(sl.numServices):
+                it = ServiceItem()
+                sl.getItem(handle, i, C.byref(it))           # getter called inside the callback, as the host does
+                items.append((it.sid, it.label.str.decode()))
+            rec["services"] = items
+        with lock:
+            events.append(rec)
+
+    L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
+    assert L.dabsdrInit(C.byref(handle)) == 0
+    for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+    L.dabsdrRegisterInputFcn(handle, C.cast(get_samples, C.c_void_p))
+    L.dabsdrRegisterDummyInputFcn(handle, C.cast(get_samples, C.c_void_p))
+    L.dabsdrRegisterNotificationCb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.dabsdrRegisterNotificationCb(handle, C.cast(on_ntf, C.c_void_p), None)
+    for name in ("dabsdr", "dabsdrRequest_GetEnsemble", "dabsdrRequest_GetServiceList", "dabsdrRequest_Exit"):
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.dabsdrRequest_Tune.argtypes = [C.c_void_p, C.c_uint32]
+    L.dabsdrRequest_SetPeriodicNotify.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32]
+    L.dabsdr(handle)
+    L.dabsdrRequest_SetPeriodicNotify(handle, 1, 0)          # every 2 frames
+    L.dabsdrRequest_Tune(handle, 225648)
+
+    def wait_for(pred, timeout=60.0):
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            with lock:
+                hit = [e for e in events if pred(e)]
+            if hit:
+                return hit
+            time.sleep(0.02)
+        raise AssertionError(f"timeout; events so far: {events[-10:]}")
+
+    wait_for(lambda e: e["nid"] == NID["TUNE"] and e.get("freq") == 225648)
+    wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)       # DABSDR_SYNC_LEVEL_FIC
+    per = wait_for(lambda e: e["nid"] == NID["PERIODIC"] and "fib_err" in e and e["level"] == 3)
+    assert per[-1]["fib_err"] == 0
+    assert abs(per[-1]["foff"] / 10.0 - cfo) < 10.0                                   # Hz, positive = above nominal
+    time.sleep(0.3)
+    L.dabsdrRequest_GetEnsemble(handle)
+    ens = wait_for(lambda e: e["nid"] == NID["ENSEMBLE_INFO"] and e["status"] == 0)[-1]
+    assert ens["ueid"] == 0x00E21234 and ens["lto"] == 2 and ens["label"].startswith("GRAFT ENS") and ens["freq"] == 225648
+    L.dabsdrRequest_GetServiceList(handle)
+    sl = wait_for(lambda e: e["nid"] == NID["SERVICE_LIST"])[-1]
+    assert sorted(s[0] for s in sl["services"]) == [0x1A01, 0x1A02]
+    assert all(lbl.startswith("SERVICE 0") for _, lbl in sl["services"])
+    L.dabsdrRequest_Exit(handle)
+    L.dabsdrDeinit.argtypes = [C.POINTER(C.c_void_p)]
+    L.dabsdrDeinit(C.byref(handle))
+    assert not handle.value

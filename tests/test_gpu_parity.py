@@ -21,10 +21,10 @@ def test_fft_bit_exact(gpu_ctx_factory):
 
 @pytest.mark.parametrize("kind,prof", [(0, (0, 3, 64)), (1, (0, 3, 64)), (1, (0, 1, 8)), (1, (0, 2, 8)), (1, (0, 2, 40)),
                                        (1, (0, 4, 72)), (1, (1, 1, 32)), (1, (1, 2, 64)), (1, (1, 3, 32)), (1, (1, 4, 96)),
-                                       (1, (0, 3, 192))])
+                                       (1, (0, 3, 192)), (1, (2, 0, 0)), (1, (2, 13, 0)), (1, (2, 38, 0)), (1, (2, 63, 0))])
 def test_viterbi_bit_exact(gpu_ctx_factory, kind, prof):
     ctx = gpu_ctx_factory(n_streams=1, max_frames=1, ring_frames=4)
-    n_coded = 2304 if kind == 0 else ob.eep_profile(*prof).n_coded
+    n_coded = 2304 if kind == 0 else ob.any_profile(*prof).n_coded
     rng = np.random.default_rng(hash(prof) & 0xFFFF)
     soft = rng.integers(-127, 128, (9, n_coded)).astype(np.int8)
     soft[1] = 0                                   # all ties
@@ -68,7 +68,8 @@ def _run_pair(ctx, streams, steps, frames, subs):
 
 
 def test_full_chain_u8_matches_oracle_and_transmitter(gpu_ctx_factory):
-    subs = [ob.subch_layout(18, 64), [[0, 0, 3, 64], [48, 1, 4, 32], [100, 0, 1, 8], [200, 0, 2, 32], [300, 0, 3, 192]]]
+    subs = [ob.subch_layout(18, 64), [[0, 0, 3, 64], [48, 1, 4, 32], [100, 0, 1, 8], [200, 0, 2, 32], [300, 0, 3, 192],
+                                      [500, 2, 22, 0], [600, 2, 5, 0]]]                      # EEP A/B and two UEP sub-channels
     streams, truth = [], []
     for s in range(2):
         iq, fib, msc = ob.tx_generate(seed=20 + s, eid=0x2000 + s, n_frames=10, subch=subs[s], delay=1000 + 77777 * s,

@@ -59,3 +59,15 @@ def test_periodic_signal_loops():
     assert o["fib_ok"].all() and o["msc_valid"].all()
     tx = {m.tobytes() for m in msc}
     assert all(m.tobytes() in tx for m in o["msc"].reshape(16, -1))
+
+
+def test_uep_subchannels_roundtrip():
+    sub = [[0, 2, 0, 0], [16, 2, 63, 0], [432, 2, 35, 0], [600, 0, 3, 64]]       # UEP indices 0, 63, 35 + one EEP
+    iq, fib, msc = ob.tx_generate(seed=6, n_frames=7, subch=sub, delay=99, snr_db=13.0, cfo_hz=-700.0)
+    s = ob.Stream(subch=sub)
+    s.push(iq)
+    o = s.process(5)
+    assert o["rc"] == 5 and o["fib_ok"].all()
+    got = o["msc"].reshape(20, -1)
+    for c in range(15, 20):
+        assert np.array_equal(got[c], msc[c - 15])

@@ -95,3 +95,22 @@ def test_fft_against_numpy():
     X = ob.fft(x)
     ref = np.fft.fft(x.astype(np.complex128))
     assert np.abs(X - ref).max() <= 2e-6 * np.abs(ref).max()       # fp32 tolerance: 2e-6 of full scale
+
+
+def test_uep_table_is_self_consistent():
+    # EN 300 401 table 8 sub-channel sizes per (bit rate, protection level 5..1)
+    sizes = {32: [16, 21, 24, 29, 35], 48: [24, 29, 35, 42, 52], 56: [29, 35, 42, 52], 64: [32, 42, 48, 58, 70],
+             80: [40, 52, 58, 70, 84], 96: [48, 58, 70, 84, 104], 112: [58, 70, 84, 104], 128: [64, 84, 96, 116, 140],
+             160: [80, 104, 116, 140, 168], 192: [96, 116, 140, 168, 208], 224: [116, 140, 168, 208, 232],
+             256: [128, 168, 192, 232, 280], 320: {5: 160, 4: 208, 2: 280}, 384: {5: 192, 3: 280, 1: 416}}
+    L = ob.lib()
+    L.dab_profile_uep.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    seen = 0
+    for idx in range(64):
+        p, kbps, lvl = ob.Profile(), C.c_int(), C.c_int()
+        assert L.dab_profile_uep(idx, C.byref(p), C.byref(kbps), C.byref(lvl)) == 0
+        table = sizes[kbps.value]
+        size = table[lvl.value] if isinstance(table, dict) else table[5 - lvl.value]
+        assert p.n_cu == size and p.n_in == 24 * kbps.value        # 24 ms of audio per CIF
+        seen += 1
+    assert seen == 64
