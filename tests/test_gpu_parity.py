@@ -147,3 +147,19 @@ def test_periodic_ring_round_trip_at_scale(gpu_ctx_factory):
             assert gv.all()
             assert all(f.tobytes() in tx[s][0] for f in gf)
             assert all(m.tobytes() in tx[s][1] for m in gm.reshape(F * 4, -1))
+
+
+def test_lane_per_codeword_path_matches_oracle(gpu_ctx_factory, monkeypatch):
+    # DABX_VIT64=1 routes every full bucket of 64 same-profile codewords through k_xgather /
+    # k_vit64_fwd / k_vit64_tb (experimental, off by default); leftovers stay on k_viterbi.
+    monkeypatch.setenv("DABX_VIT64", "1")
+    subs = [ob.subch_layout(18, 64), [[0, 2, 22, 0], [100, 0, 3, 64], [200, 1, 4, 32]]]
+    streams, truth = [], []
+    for s in range(2):
+        iq, fib, msc = ob.tx_generate(seed=60 + s, eid=0x2100 + s, n_frames=10, subch=subs[s], delay=500 + 3333 * s,
+                                      snr_db=14.0, cfo_hz=1000.0 - 3000.0 * s)
+        streams.append(iq); truth.append((fib, msc))
+    ctx = gpu_ctx_factory(n_streams=2, fmt=0, ring_frames=16, max_frames=4)
+    res = _run_pair(ctx, streams, steps=2, frames=4, subs=subs)
+    for i, (s, gf, gok, gm, gv) in enumerate(res):
+        assert gok.all() and np.array_equal(gf, truth[s][0][4 * (i // 2):4 * (i // 2) + 4])
