@@ -11,6 +11,7 @@
 #include "../../include/dabsdr_amd.h"
 #include "../../include/dabx.h"
 #include "fig_db.hpp"
+#include "superframe.hpp"
 
 #include <pthread.h>
 
@@ -66,6 +67,11 @@ struct dabsdr_s {
     uint32_t fib_err_acc = 0;
     figdb::Database db;
     uint32_t sel_sid = 0; int sel_scids = -1; bool sel_active = false;
+    int sel_ascty = 0, sel_kbps = 0;
+    dabsdrDecoderId_t sel_id = DABSDR_ID_AUDIO_PRIMARY;
+    dabplus::Decoder aac;                 // DAB+ super frame -> access units
+    dabplus::Stats last_stats;
+    uint32_t audio_bytes_acc = 0;
     std::vector<figdb::Service> list_snapshot;       // for the list getters (valid during a callback)
     std::vector<figdb::Component> comp_snapshot;
     uint32_t comp_sid = 0;
@@ -237,7 +243,13 @@ void handle_request(dabsdr_s *h, const Request &r)
                 dabx_subch_t sc = {it->second.start, it->second.option, it->second.level, it->second.kbps};
                 if (!it->second.long_form) sc = {it->second.start, 2, it->second.uep_index, 0};   // UEP short form
                 st = dabx_set_subchannels(h->ctx, 0, 1, &sc) >= 0 ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_SERVICE_NOT_SUPPORTED;
-                if (st == DABSDR_NSTAT_SUCCESS) { h->sel_sid = r.a; h->sel_scids = r.b; h->sel_active = true; }
+                if (st == DABSDR_NSTAT_SUCCESS) {
+                    h->sel_sid = r.a; h->sel_scids = r.b; h->sel_active = true;
+                    h->sel_ascty = c.ascty_dscty; h->sel_kbps = it->second.kbps;
+                    h->sel_id = static_cast<dabsdrDecoderId_t>(r.c);
+                    h->aac.configure(h->sel_kbps);
+                    h->last_stats = dabplus::Stats();
+                }
                 break;
             }
         }
@@ -314,6 +326,31 @@ void after_step(dabsdr_s *h)
         notify(h, DABSDR_NID_SYNC_STATUS, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
     }
     h->fib_err_acc += static_cast<uint32_t>(12 - good);
+    // selected audio service: the CIF's decoded sub-channel bytes -> access units -> audio callback
+    if (h->sel_active && h->audio_cb && h->sel_kbps > 0) {
+        std::vector<uint8_t> msc(4 * static_cast<size_t>(3 * h->sel_kbps));
+        uint8_t valid[4];
+        if (dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK) {
+            for (int c = 0; c < 4; ++c) {
+                if (!valid[c]) continue;
+                const uint8_t *frame = msc.data() + static_cast<size_t>(c) * 3 * h->sel_kbps;
+                if (h->sel_ascty == 63) {                  // DAB+ (HE-AAC): super frames
+                    h->aac.push(frame, [&](const dabplus::AccessUnit &au) {
+                        dabsdrAudioCBData_t d;
+                        d.id = h->sel_id; d.ASCTy = 63; d.header.raw = au.header; d.auLen = au.len; d.pAuData = au.data;
+                        h->audio_bytes_acc += au.len;
+                        h->audio_cb(&d, h->audio_ctx);
+                    });
+                } else {                                   // MPEG-1/2 Layer II: one logical frame per call
+                    dabsdrAudioCBData_t d;
+                    d.id = h->sel_id; d.ASCTy = static_cast<uint8_t>(h->sel_ascty); d.header.raw = 0;
+                    d.auLen = static_cast<uint16_t>(3 * h->sel_kbps); d.pAuData = frame;
+                    h->audio_bytes_acc += d.auLen;
+                    h->audio_cb(&d, h->audio_ctx);
+                }
+            }
+        }
+    }
     if (h->period_log2 >= 0 && ++h->period_frames >= (1 << h->period_log2)) {
         dabsdrNtfPeriodic_t p;
         std::memset(&p, 0, sizeof p);
@@ -326,6 +363,14 @@ void after_step(dabsdr_s *h)
             p.secMsec = static_cast<uint16_t>((h->db.ens.seconds << 10) | h->db.ens.ms);
         }
         p.fibErrorCntr = static_cast<uint16_t>(h->fib_err_acc);
+        const dabplus::Stats &now = h->aac.stats;
+        p.mscCrcOkCntr = static_cast<uint8_t>(now.au_ok - h->last_stats.au_ok);
+        p.mscCrcErrorCntr = static_cast<uint8_t>(now.au_crc_err - h->last_stats.au_crc_err);
+        p.rsUncorrectableCntr = static_cast<uint16_t>(now.rs_uncorrectable - h->last_stats.rs_uncorrectable);
+        p.rsBitErrors = static_cast<uint16_t>(now.rs_corrected - h->last_stats.rs_corrected);
+        p.rsBytes = static_cast<uint16_t>((now.superframes - h->last_stats.superframes) * 120u * static_cast<unsigned>(h->sel_kbps / 8));
+        p.audioServiceBytes = static_cast<uint16_t>(h->audio_bytes_acc);
+        h->last_stats = now; h->audio_bytes_acc = 0;
         notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, &p, sizeof p);
         h->period_frames = 0; h->fib_err_acc = 0;
     }
@@ -441,6 +486,28 @@ void dabsdrRequest_Exit(dabsdrHandle_t h)
     if (!h) return;
     h->exit_req.store(true);
     post(h, {Req::Exit, 0, 0, 0});
+}
+
+// test hook (CPU only): run logical frames of a DAB+ sub-channel through the super frame decoder.
+// out receives records {header, len lo, len hi, data[len]}; stats[6] = superframes, au_ok,
+// au_crc_err, rs_corrected, rs_uncorrectable, sync_loss.  Returns bytes written or -1.
+DABSDR_API int dabsdr_amd_superframe_decode(const uint8_t *frames, int n_frames, int kbps, uint8_t *out, int cap, uint32_t *stats)
+{
+    dabplus::Decoder dec(kbps);
+    int used = 0;
+    bool overflow = false;
+    for (int f = 0; f < n_frames; ++f)
+        dec.push(frames + static_cast<size_t>(f) * 3 * kbps, [&](const dabplus::AccessUnit &au) {
+            if (used + 3 + au.len > cap) { overflow = true; return; }
+            out[used++] = au.header; out[used++] = static_cast<uint8_t>(au.len); out[used++] = static_cast<uint8_t>(au.len >> 8);
+            std::memcpy(out + used, au.data, au.len);
+            used += au.len;
+        });
+    if (stats) {
+        stats[0] = dec.stats.superframes; stats[1] = dec.stats.au_ok; stats[2] = dec.stats.au_crc_err;
+        stats[3] = dec.stats.rs_corrected; stats[4] = dec.stats.rs_uncorrectable; stats[5] = dec.stats.sync_loss;
+    }
+    return overflow ? -1 : used;
 }
 
 // test hook (CPU only): parse FIBs and print the ensemble as text, see tests/test_figdb.py

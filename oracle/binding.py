@@ -46,6 +46,9 @@ def lib():
         L.dab_crc16.argtypes = [C.c_void_p, C.c_int]
         L.dab_conv_output.argtypes = [C.c_int, C.c_int]
         L.dab_profile_eep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dab_profile_any.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dab_superframe_build.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dab_rs_encode_120_110.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -53,7 +56,7 @@ def lib():
 class TxCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("eid", C.c_int32), ("n_frames", C.c_int32), ("n_subch", C.c_int32),
                 ("delay", C.c_int32), ("loop", C.c_int32), ("fmt", C.c_int32), ("snr_db", C.c_double),
-                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64)]
+                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64), ("payload_given", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -90,8 +93,9 @@ def subch_layout(n=18, kbps=64, option=0, level=3):
 
 
 def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0, snr_db=30.0, cfo_hz=0.0,
-                rms=28.0):
-    """Synthetic Mode-I signal.  Returns (iq, fib[n_frames,12,32], msc[n_frames*4, bytes_per_cif])."""
+                rms=28.0, payload=None):
+    """Synthetic Mode-I signal.  Returns (iq, fib[n_frames,12,32], msc[n_frames*4, bytes_per_cif]).
+    payload: optional uint8 array [n_frames*4, bytes_per_cif] to transmit instead of random bytes."""
     L = lib()
     cfg = TxCfg()
     cfg.seed, cfg.eid, cfg.n_frames, cfg.n_subch = seed, eid, n_frames, len(subch)
@@ -107,6 +111,9 @@ def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0
     iq = np.zeros(nsamp * 2, dtype=np.int16 if fmt else np.uint8)
     fib = np.zeros((n_frames, 12, 32), dtype=np.uint8)
     msc = np.zeros((n_frames * 4, max(mb, 1)), dtype=np.uint8)
+    if payload is not None:
+        msc[:, :mb] = np.asarray(payload, dtype=np.uint8).reshape(n_frames * 4, mb)
+        cfg.payload_given = 1
     rc = L.dab_tx_generate(C.byref(cfg), iq.ctypes.data, fib.ctypes.data, msc.ctypes.data)
     if rc:
         raise RuntimeError(f"dab_tx_generate failed: {rc}")
@@ -181,3 +188,26 @@ def decode_linear(soft, kind=0, option=0, level=3, kbps=64):
     if n < 0:
         raise ValueError("bad profile")
     return out[:n].copy()
+
+
+def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0):
+    """Random DAB+ audio super frames for a kbps sub-channel.
+    Returns (bytes [n_superframes*5, 3*kbps] = one row per logical frame, list of AU payloads)."""
+    L = lib()
+    s = kbps // 8
+    num_aus = (3 if sbr else 6) if dac_rate else (2 if sbr else 4)
+    first = (6 if sbr else 11) if dac_rate else (5 if sbr else 8)
+    room = 110 * s - first - 2 * num_aus
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_superframes, 120 * s), dtype=np.uint8)
+    aus = []
+    for f in range(n_superframes):
+        cuts = np.sort(rng.choice(np.arange(8, room - 8), num_aus - 1, replace=False)) if num_aus > 1 else np.array([], dtype=int)
+        lens = np.diff(np.concatenate([[0], cuts, [room]])).astype(np.int32)
+        data = [rng.integers(0, 256, int(n), dtype=np.uint8) for n in lens]
+        ptrs = (C.c_void_p * num_aus)(*[d.ctypes.data for d in data])
+        ln = (C.c_int * num_aus)(*[int(n) for n in lens])
+        rc = L.dab_superframe_build(s, dac_rate, sbr, ch_mode, ps, 0, ptrs, ln, out[f].ctypes.data)
+        assert rc == 0
+        aus += data
+    return out.reshape(n_superframes * 5, 24 * s), aus

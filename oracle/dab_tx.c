@@ -24,7 +24,8 @@ typedef struct {
     double   snr_db;       /* >= 100: noiseless                        */
     double   cfo_hz;
     double   rms;          /* complex RMS of the signal in LSB         */
-    int32_t  subch[64][4]; /* {start_cu, option(0=A,1=B), level, kbps} */
+    int32_t  subch[64][4]; /* {start_cu, option(0=A,1=B,2=UEP), level, kbps} */
+    int32_t  payload_given;/* 1: msc_out already holds the payload to transmit    */
 } dab_tx_cfg_t;
 
 /* ---- deterministic PRNG (splitmix64) ---- */
@@ -234,7 +235,7 @@ int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *
         for (int s = 0; s < c->n_subch; s++) {
             uint8_t *pay = msc_out + (size_t)r * msc_bytes + off_bytes[s];
             int nb = prof[s].n_in / 8;
-            for (int i = 0; i < nb; i += 8) {
+            for (int i = 0; i < nb && !c->payload_given; i += 8) {
                 uint64_t x = sm64(&rng);
                 for (int j = 0; j < 8 && i + j < nb; j++) pay[i + j] = (uint8_t)(x >> (8 * j));
             }

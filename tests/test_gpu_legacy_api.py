@@ -135,3 +135,85 @@ def test_tune_lock_ensemble_and_service_list():
     L.dabsdrDeinit.argtypes = [C.POINTER(C.c_void_p)]
     L.dabsdrDeinit(C.byref(handle))
     assert not handle.value
+
+
+def test_service_selection_delivers_dabplus_access_units():
+    """tune -> select the DAB+ service -> the audio callback (dabsdr.h:390) receives exactly the
+    transmitted access units (header 0x70 = 48 kHz DAC, SBR, stereo), as radiocontrol.cpp:2542 expects."""
+    L = aa.load_library()
+    sub = [[0, 0, 3, 64], [48, 1, 4, 32]]
+    n_frames = 30
+    sf_rows, aus_tx = ob.superframes(64, n_frames * 4 // 5, seed=11)
+    payload = np.zeros((n_frames * 4, 192 + 96), dtype=np.uint8)
+    payload[:len(sf_rows), :192] = sf_rows
+    payload[:, 192:] = np.random.default_rng(2).integers(0, 256, (n_frames * 4, 96), dtype=np.uint8)
+    iq, fib, _ = ob.tx_generate(seed=78, eid=0x1235, n_frames=n_frames, subch=sub, delay=3000, snr_db=22.0, cfo_hz=-800.0, payload=payload)
+    samples = iq.astype(np.float32) - 128.0
+    pos, gate = [0], threading.Event()
+    got, events, lock = [], [], threading.Lock()
+    handle = C.c_void_p()
+
+    class AudioCB(C.Structure):
+        _fields_ = [("id", C.c_int), ("ASCTy", C.c_uint8), ("header", C.c_uint8), ("auLen", C.c_uint16), ("pAuData", C.POINTER(C.c_uint8))]
+
+    @C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint16)
+    def get_samples(buf, n):
+        if pos[0] >= 2 * 8 * 196608 and not gate.is_set():
+            gate.wait(30.0)                                  # hold the un-paced library until the service is selected
+        out = np.ctypeslib.as_array(buf, shape=(2 * n,))
+        take = samples[pos[0]:pos[0] + 2 * n]
+        out[:len(take)] = take
+        out[len(take):] = 0.0
+        pos[0] += 2 * n
+
+    @C.CFUNCTYPE(None, C.POINTER(Ntf), C.c_void_p)
+    def on_ntf(p, ctx):
+        with lock:
+            events.append((p.contents.nid, p.contents.status))
+
+    @C.CFUNCTYPE(None, C.POINTER(AudioCB), C.c_void_p)
+    def on_audio(p, ctx):
+        a = p.contents
+        with lock:
+            got.append((a.id, a.ASCTy, a.header, bytes(np.ctypeslib.as_array(a.pAuData, shape=(a.auLen,)))))
+
+    L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
+    assert L.dabsdrInit(C.byref(handle)) == 0
+    for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        getattr(L, name)(handle, C.cast(get_samples, C.c_void_p))
+    for name, fn in (("dabsdrRegisterNotificationCb", on_ntf), ("dabsdrRegisterAudioCb", on_audio)):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        getattr(L, name)(handle, C.cast(fn, C.c_void_p), None)
+    L.dabsdr.argtypes = [C.c_void_p]
+    L.dabsdrRequest_Tune.argtypes = [C.c_void_p, C.c_uint32]
+    L.dabsdrRequest_ServiceSelection.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8, C.c_int]
+    L.dabsdrRequest_Exit.argtypes = [C.c_void_p]
+    L.dabsdr(handle)
+    L.dabsdrRequest_Tune(handle, 225648)
+
+    def wait_until(pred, timeout=60.0):
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            with lock:
+                if pred():
+                    return
+            time.sleep(0.02)
+        raise AssertionError(f"timeout: events={events[-8:]} n_au={len(got)}")
+
+    wait_until(lambda: (NID["SYNC_STATUS"], 0) in events)
+    time.sleep(0.5)                                          # FIG database fills while the gate holds the input at frame 8
+    L.dabsdrRequest_ServiceSelection(handle, 0x1A01, 0, 0)
+    wait_until(lambda: (NID["SERVICE_SELECTION"], 0) in events)
+    gate.set()
+    wait_until(lambda: len(got) >= 24)
+    L.dabsdrRequest_Exit(handle)
+    L.dabsdrDeinit.argtypes = [C.POINTER(C.c_void_p)]
+    L.dabsdrDeinit(C.byref(handle))
+    with lock:
+        rx = list(got)
+    assert all(g[0] == 0 and g[1] == 63 and g[2] == 0x70 for g in rx)
+    tx = [a.tobytes() for a in aus_tx]
+    first = tx.index(rx[0][3])                               # first AU delivered after the interleaver filled
+    assert first % 3 == 0                                    # starts on a super frame boundary (3 AUs per super frame)
+    assert [g[3] for g in rx] == tx[first:first + len(rx)]
