@@ -381,20 +381,28 @@ void worker_main(dabsdr_s *h)
     pthread_setname_np(pthread_self(), "dabsdr");
     h->fbuf.resize(2 * kPullChunk);
     h->sbuf.resize(2 * kPullChunk);
-    while (!h->exit_req.load()) {
+    // requests are served between input calls (every 8 ms of signal), like the reference, whose
+    // reads never exceed one OFDM symbol: a host that paces or gates its input still gets answers
+    auto serve = [h](bool may_block) -> bool {
         std::deque<Request> todo;
         {
             std::unique_lock<std::mutex> lk(h->mu);
-            if (h->frequency == 0 && h->queue.empty()) h->cv.wait(lk, [&] { return !h->queue.empty() || h->exit_req.load(); });
+            if (may_block && h->queue.empty()) h->cv.wait(lk, [&] { return !h->queue.empty() || h->exit_req.load(); });
             todo.swap(h->queue);
         }
         for (const Request &r : todo) {
-            if (r.kind == Req::Exit) return;
+            if (r.kind == Req::Exit) return false;
             handle_request(h, r);
         }
+        return true;
+    };
+    while (!h->exit_req.load()) {
+        if (!serve(h->frequency == 0)) return;
         if (h->frequency == 0 || !h->ctx || !h->input) continue;
         // one transmission frame of input, then decode whatever is complete
         for (int got = 0; got < DABX_FRAME_SAMPLES && !h->exit_req.load(); got += kPullChunk) {
+            if (got && !serve(false)) return;
+            if (h->frequency == 0 || !h->ctx) break;
             h->input(h->fbuf.data(), static_cast<uint16_t>(kPullChunk));
             convert(h, h->fbuf.data(), h->sbuf.data(), 2 * kPullChunk);
             if (dabx_push(h->ctx, 0, h->sbuf.data(), kPullChunk, 0) != DABX_OK) break;

@@ -159,7 +159,7 @@ def test_service_selection_delivers_dabplus_access_units():
     @C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint16)
     def get_samples(buf, n):
         if pos[0] >= 2 * 8 * 196608 and not gate.is_set():
-            gate.wait(30.0)                                  # hold the un-paced library until the service is selected
+            gate.wait(0.05)                                  # pace the un-paced library until the service is selected
         out = np.ctypeslib.as_array(buf, shape=(2 * n,))
         take = samples[pos[0]:pos[0] + 2 * n]
         out[:len(take)] = take
