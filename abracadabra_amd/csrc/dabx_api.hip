@@ -6,6 +6,7 @@
 #include "dabx_kernels.hip"
 #include "dabx_vit64.hip"
 #include "dabx_spec.hpp"
+#include "rawfile.hpp"
 #include "../../include/dabx.h"
 
 #include <algorithm>
@@ -605,6 +606,14 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     HIPCHK(hipMemcpy(out, d_out, static_cast<size_t>(n_cw) * (p.n_in / 8), hipMemcpyDeviceToHost));
     (void)hipFree(d_soft); (void)hipFree(d_info); (void)hipFree(d_scr); (void)hipFree(d_out);
     return p.n_in / 8;
+}
+
+int dabx_rawfile_probe(const uint8_t *head, int n_bytes, dabx_rawfile_info_t *info)
+{
+    if (!head || n_bytes < 0 || !info) return DABX_E_ARG;
+    const rawfile::Info r = rawfile::probe(head, n_bytes);
+    *info = {r.has_header, r.fmt, r.data_offset, r.channel_count, r.samplerate, r.frequency_khz};
+    return DABX_OK;
 }
 
 int dabx_enable_timing(dabx_ctx *c, int on)

@@ -21,7 +21,7 @@ DABX_SYMBOLS = [
     "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_ring_ptr",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
-    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing",
+    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe",
 ]
 
 
@@ -41,6 +41,22 @@ class SubCh(C.Structure):
 class StreamState(C.Structure):
     _fields_ = [("pos", C.c_int64), ("inc", C.c_int32), ("locked", C.c_int32), ("cif", C.c_int64),
                 ("bad", C.c_int32), ("reserved", C.c_int32), ("wr", C.c_int64)]
+
+
+class RawFileInfo(C.Structure):
+    _fields_ = [("has_header", C.c_int32), ("fmt", C.c_int32), ("data_offset", C.c_int64), ("channel_count", C.c_int64),
+                ("samplerate", C.c_int32), ("frequency_khz", C.c_int32)]
+
+
+def rawfile_probe(head):
+    """Inspect the first bytes of a .raw/.uff file (reference: rawfileinput.cpp:90-134)."""
+    L = load_library()
+    head = np.frombuffer(bytes(head[:4096]), dtype=np.uint8)
+    info = RawFileInfo()
+    L.dabx_rawfile_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(RawFileInfo)]
+    _chk(L.dabx_rawfile_probe(head.ctypes.data, head.size, C.byref(info)))
+    return dict(has_header=bool(info.has_header), fmt=info.fmt, data_offset=info.data_offset, channel_count=info.channel_count,
+                samplerate=info.samplerate, frequency_khz=info.frequency_khz)
 
 
 def library_path():

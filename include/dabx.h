@@ -144,6 +144,21 @@ DABX_API int dabx_fft2048(dabx_ctx *ctx, const float *in, float *out, int n_vec)
 DABX_API int dabx_viterbi(dabx_ctx *ctx, int kind, int option, int level, int kbps,
                           const int8_t *soft, int n_cw, uint8_t *out);
 
+/* Raw-file front end: the reference's RawFileInput accepts headerless `.raw` files and `.uff`
+ * files whose first 2048 bytes hold a zero-padded XML description (reference:
+ * src/input/rawfileinput.cpp:90-134, writer src/input/inputdevicerecorder.cpp:195-263).
+ * dabx_rawfile_probe inspects the first bytes of a file and tells where the samples start and in
+ * which DABX_FMT_* they are; fmt = -1 and data_offset = 0 for a headerless file. */
+typedef struct {
+    int32_t has_header;
+    int32_t fmt;
+    int64_t data_offset;
+    int64_t channel_count;
+    int32_t samplerate;
+    int32_t frequency_khz;
+} dabx_rawfile_info_t;
+DABX_API int dabx_rawfile_probe(const uint8_t *head, int n_bytes, dabx_rawfile_info_t *info);
+
 /* Timing of the last step, HIP events on the context's stream (ms):
  * [0] acquire+sync, [1] FFT/demap, [2] Viterbi, [3] CRC/state, [4] whole step */
 DABX_API int dabx_last_timing(dabx_ctx *ctx, float ms[5]);
