@@ -72,6 +72,8 @@ struct dabsdr_s {
     dabplus::Decoder aac;                 // DAB+ super frame -> access units
     dabplus::Stats last_stats;
     uint32_t audio_bytes_acc = 0;
+    bool spectrum_on = false;
+    std::vector<float> spectrum;
     std::vector<figdb::Service> list_snapshot;       // for the list getters (valid during a callback)
     std::vector<figdb::Component> comp_snapshot;
     uint32_t comp_sid = 0;
@@ -173,6 +175,7 @@ void handle_request(dabsdr_s *h, const Request &r)
                 dabx_destroy(h->ctx);
                 h->ctx = nullptr;
                 if (dabx_create(&cfg, &h->ctx) != DABX_OK) h->ctx = nullptr;
+                else if (h->spectrum_on) dabx_enable_spectrum(h->ctx, 1);
             }
             uint32_t f = r.a;
             notify(h, DABSDR_NID_TUNE, h->ctx ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_GENERIC_ERROR, &f, 0);
@@ -273,8 +276,11 @@ void handle_request(dabsdr_s *h, const Request &r)
         h->period_frames = 0; h->fib_err_acc = 0;
         notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, nullptr, 0);      // acknowledgement, no payload
         break;
-    case Req::SetTII:
     case Req::SignalSpectrum:
+        h->spectrum_on = r.a != 0;
+        if (h->ctx) dabx_enable_spectrum(h->ctx, h->spectrum_on ? 1 : 0);
+        break;
+    case Req::SetTII:                     // TII detection: not implemented yet
     case Req::Exit:
         break;
     }
@@ -326,6 +332,10 @@ void after_step(dabsdr_s *h)
         notify(h, DABSDR_NID_SYNC_STATUS, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
     }
     h->fib_err_acc += static_cast<uint32_t>(12 - good);
+    if (h->spectrum_on && h->spec_cb) {
+        h->spectrum.resize(2048);
+        if (dabx_get_spectrum(h->ctx, 0, h->spectrum.data()) == DABX_OK) h->spec_cb(h->spectrum.data(), DABSDR_SPECT_SIGNAL, h->spec_ctx);
+    }
     // selected audio service: the CIF's decoded sub-channel bytes -> access units -> audio callback
     if (h->sel_active && h->audio_cb && h->sel_kbps > 0) {
         std::vector<uint8_t> msc(4 * static_cast<size_t>(3 * h->sel_kbps));

@@ -357,6 +357,15 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         load_window<FMT>(v, T, ring, C.ring_len, w0i, 0u, inc, t);
         fft2048(v, buf, t, tw);
     }
+    // optional signal spectrum of the last frame (reference: dabsdrSpectrumCBFunc_t, dabsdr.h:393):
+    // linear power of the un-normalised 2048-point FFT, natural bin order
+    if (C.spectrum && f == n_frames - 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = v[e].r * v[e].r, b = v[e].i * v[e].i;
+            C.spectrum[(size_t)s * TU + T.bin_of_pos[8 * t + e]] = a + b;
+        }
+    }
     // 3. conj(X * conj(P)) in natural order, second FFT -> impulse response
     __syncthreads();
 #pragma unroll

@@ -150,6 +150,12 @@ class Stream:
         iq = np.ascontiguousarray(iq)
         self.L.orx_push(self.h, iq.ctypes.data, iq.size // 2)
 
+    def spectrum(self):
+        out = np.zeros(2048, dtype=np.float32)
+        self.L.orx_get_spectrum.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orx_get_spectrum(self.h, out.ctypes.data)
+        return out
+
     def state(self):
         st = np.zeros(6, dtype=np.int64)
         self.L.orx_get_state(self.h, st.ctypes.data)

@@ -163,3 +163,19 @@ def test_lane_per_codeword_path_matches_oracle(gpu_ctx_factory, monkeypatch):
     res = _run_pair(ctx, streams, steps=2, frames=4, subs=subs)
     for i, (s, gf, gok, gm, gv) in enumerate(res):
         assert gok.all() and np.array_equal(gf, truth[s][0][4 * (i // 2):4 * (i // 2) + 4])
+
+
+def test_signal_spectrum_matches_oracle(gpu_ctx_factory):
+    sub = ob.subch_layout(2, 64)
+    iq, _, _ = ob.tx_generate(seed=70, n_frames=4, subch=sub, delay=1500, snr_db=20.0, cfo_hz=2500.0)
+    ctx = gpu_ctx_factory(n_streams=1, fmt=0, ring_frames=8, max_frames=2)
+    ctx.enable_spectrum(True)
+    ctx.push(0, iq)
+    ctx.process(2)
+    orc = ob.Stream(ring_len=8 * ob.TF)
+    orc.push(iq)
+    orc.process(2)
+    g, o = ctx.spectrum(0), orc.spectrum()
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))              # bit for bit
+    band = np.r_[1:769, 2048 - 768:2048]
+    assert g[band].mean() > 50 * g[800:1248].mean()                          # 1536 carriers stand out of the guard band
