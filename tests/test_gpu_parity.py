@@ -179,3 +179,33 @@ def test_signal_spectrum_matches_oracle(gpu_ctx_factory):
     assert np.array_equal(g.view(np.uint32), o.view(np.uint32))              # bit for bit
     band = np.r_[1:769, 2048 - 768:2048]
     assert g[band].mean() > 50 * g[800:1248].mean()                          # 1536 carriers stand out of the guard band
+
+
+def test_config2_64_streams_fft_demap_bit_exact(gpu_ctx_factory):
+    """BASELINE configs[1]: 64 synthetic Mode-I IQ streams batched through sync + 2048-FFT + DQPSK
+    demap; every soft bit equals the oracle's, and at 25 dB the hard decisions of the FIC symbols
+    re-encode to the transmitted FIBs (checked through the decoded FIBs)."""
+    S = 64
+    ctx = gpu_ctx_factory(n_streams=S, fmt=0, ring_frames=8, max_frames=1)
+    rng = np.random.default_rng(64)
+    sub = ob.subch_layout(3, 64)
+    bad = 0
+    for s in range(S):
+        iq, fib, _ = ob.tx_generate(seed=300 + s, eid=0x5000 + s, n_frames=3, subch=sub, delay=int(rng.integers(0, 150000)), snr_db=25.0,
+                                    cfo_hz=float(rng.uniform(-5000, 5000)))
+        ctx.set_subchannels(s, sub)
+        ctx.push(s, iq)
+        ctx.truth = getattr(ctx, "truth", {})
+        ctx.truth[s] = (iq, fib)
+    ctx.process(1)
+    for s in range(S):
+        iq, fib = ctx.truth[s]
+        orc = ob.Stream(subch=sub, ring_len=ctx.ring_samples)
+        orc.push(iq)
+        o = orc.process(1)
+        assert np.array_equal(ctx.sync(s), o["sync"])
+        assert np.array_equal(ctx.fic_soft(s), o["fic_soft"]) and np.array_equal(ctx.msc_soft(s), o["msc_soft"])
+        gf, gok = ctx.fib(s)
+        bad += int((~gok.astype(bool)).sum())
+        assert np.array_equal(gf, fib[:1])
+    assert bad == 0
