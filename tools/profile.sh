@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun): kernel trace + separate PMC passes.
-# Usage: bash tools_profile.sh <tag>     -> writes summaries under gpurun_out/prof_<tag>_*
+# Usage: bash tools/profile.sh <tag>     -> writes summaries under gpurun_out/prof_<tag>_*
 set -o pipefail
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
