@@ -319,13 +319,11 @@ void after_step(dabsdr_s *h)
     for (int i = 0; i < 12; ++i)
         if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
     const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
-    // SNR estimate from the impulse response: peak power against the rest
+    // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy
     int16_t snr10 = 0;
-    if (rec.total > 0.0f && rec.peak > 0.0f) {
-        const float rest = rec.total - rec.peak / 1.0f;
-        const float ratio = rest > 0.0f ? rec.peak / rest : 1e6f;
-        snr10 = static_cast<int16_t>(std::fmin(400.0f, std::fmax(-100.0f, 100.0f * std::log10(ratio / 1536.0f * 1536.0f) / 10.0f)));
-    }
+    if (rec.e_null > 0 && rec.e_sig > rec.e_null)
+        snr10 = static_cast<int16_t>(std::lround(100.0 * std::log10(static_cast<double>(rec.e_sig - rec.e_null) / static_cast<double>(rec.e_null))));
+    else if (rec.e_sig > 0 && rec.e_null == 0) snr10 = 600;
     if (lvl != h->sync_level) {
         h->sync_level = lvl;
         dabsdrNtfSyncStatus_t s = {lvl, snr10};
@@ -369,7 +367,7 @@ void after_step(dabsdr_s *h)
         // inc is 2^-32 turn per sample at 2.048 MHz; the host wants Hz * 10
         p.freqOffset = static_cast<int32_t>(std::llround(static_cast<double>(st.inc) * 2048000.0 * 10.0 / 4294967296.0));
         if (h->db.ens.utc_valid) {
-            p.dateHoursMinutes = (h->db.ens.mjd << 11) | (static_cast<uint32_t>(h->db.ens.hours) << 6) | static_cast<uint32_t>(h->db.ens.minutes);
+            p.dateHoursMinutes = h->db.ens.date_hours_minutes & 0x7FFFFFFFu;
             p.secMsec = static_cast<uint16_t>((h->db.ens.seconds << 10) | h->db.ens.ms);
         }
         p.fibErrorCntr = static_cast<uint16_t>(h->fib_err_acc);
@@ -535,8 +533,8 @@ DABSDR_API int dabsdr_amd_fig_dump(const uint8_t *fibs, int n_fibs, char *out, i
     for (int i = 0; i < n_fibs; ++i) db.parse_fib(fibs + 32 * i);
     std::string s;
     char line[160];
-    std::snprintf(line, sizeof line, "ensemble eid=%04X ecc=%02X lto=%d label='%s' cif=%d\n", db.ens.eid & 0xFFFF, db.ens.ecc,
-                  db.ens.lto, db.ens.label.c_str(), db.ens.cif_count);
+    std::snprintf(line, sizeof line, "ensemble eid=%04X ecc=%02X lto=%d label='%s' cif=%d utc=%u %02d:%02d:%02d.%03d\n", db.ens.eid & 0xFFFF,
+                  db.ens.ecc, db.ens.lto, db.ens.label.c_str(), db.ens.cif_count, db.ens.mjd, db.ens.hours, db.ens.minutes, db.ens.seconds, db.ens.ms);
     s += line;
     for (const auto &kv : db.subch) {
         std::snprintf(line, sizeof line, "subch id=%d start=%d size=%d opt=%d level=%d kbps=%d\n", kv.second.id, kv.second.start,

@@ -31,6 +31,7 @@ struct DevSync {        // same layout as dabx_sync_rec_t
     int32_t inc, flags, peak_idx, m_int;
     float peak, total;
     int64_t cp_re, cp_im;
+    int64_t e_null, e_sig;
 };
 
 struct DevWork {        // one Viterbi codeword = one wave

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
     __shared__ float2 buf[FFT_LDS];
     __shared__ float2 nat[TU];
     __shared__ float red[4];
-    __shared__ int64_t red64[8];
+    __shared__ int64_t red64[16];
     __shared__ int32_t sh_inc;
     __shared__ float pk_v[4];
     __shared__ int pk_i[4];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
     const int64_t pos_f = st.pos + (int64_t)f * TF;
 
     // 1. guard-interval correlation over the PRS and the three FIC symbols
-    int64_t cre = 0, cim = 0;
+    int64_t cre = 0, cim = 0, en = 0, es = 0;
     {
         const int64_t g0 = wrap(pos_f + TNULL, C.ring_len);
         for (int k = t; k < 4 * 408; k += 256) {
@@ -302,12 +302,28 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
             cre += (int64_t)i1 * i2 + (int64_t)q1 * q2;
             cim += (int64_t)q1 * i2 - (int64_t)i1 * q2;
         }
+        // sample energy inside the null symbol and inside the PRS (SNR estimate for the host)
+        const int64_t p0 = wrap(pos_f, C.ring_len);
+        for (int n = t; n < TU; n += 256) {
+            int64_t a = p0 + 128 + n, b = p0 + TNULL + TG + n;
+            if (a >= C.ring_len) a -= C.ring_len;
+            if (b >= C.ring_len) b -= C.ring_len;
+            int i1, q1, i2, q2;
+            sample<FMT>(ring, a, i1, q1); sample<FMT>(ring, b, i2, q2);
+            en += (int64_t)i1 * i1 + (int64_t)q1 * q1;
+            es += (int64_t)i2 * i2 + (int64_t)q2 * q2;
+        }
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { cre += __shfl_xor(cre, d, 64); cim += __shfl_xor(cim, d, 64); }
-        if ((t & 63) == 0) { red64[2 * (t >> 6)] = cre; red64[2 * (t >> 6) + 1] = cim; }
+        for (int d = 1; d < 64; d <<= 1) {
+            cre += __shfl_xor(cre, d, 64); cim += __shfl_xor(cim, d, 64);
+            en += __shfl_xor(en, d, 64); es += __shfl_xor(es, d, 64);
+        }
+        if ((t & 63) == 0) { red64[4 * (t >> 6)] = cre; red64[4 * (t >> 6) + 1] = cim; red64[4 * (t >> 6) + 2] = en; red64[4 * (t >> 6) + 3] = es; }
         __syncthreads();
-        cre = red64[0] + red64[2] + red64[4] + red64[6];
-        cim = red64[1] + red64[3] + red64[5] + red64[7];
+        cre = red64[0] + red64[4] + red64[8] + red64[12];
+        cim = red64[1] + red64[5] + red64[9] + red64[13];
+        en = red64[2] + red64[6] + red64[10] + red64[14];
+        es = red64[3] + red64[7] + red64[11] + red64[15];
     }
     if (t == 0) {
         int32_t A = cordic(cim, cre, T.cordic);
@@ -409,6 +425,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         r.peak_idx = pidx; r.m_int = m_best;
         r.peak = peak; r.total = total;
         r.cp_re = cre; r.cp_im = cim;
+        r.e_null = en; r.e_sig = es;
         rec = r;
     }
 }

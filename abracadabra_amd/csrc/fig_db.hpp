@@ -53,6 +53,8 @@ struct Ensemble {
     std::string label;
     uint16_t label_flag = 0;
     uint32_t mjd = 0; int hours = 0, minutes = 0, seconds = 0, ms = 0; bool utc_valid = false;
+    uint32_t date_hours_minutes = 0;  // first 32 bits of FIG 0/10 as sent: the host decodes MJD at bits 30-14,
+                                      // hours at 10-6, minutes at 5-0 (reference: src/dabtables.cpp:124-134)
 };
 
 class Database {
@@ -177,6 +179,7 @@ private:
             break;
         case 10:
             if (n >= 4) {
+                ens.date_hours_minutes = (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3];
                 ens.mjd = ((uint32_t(p[0]) & 0x7F) << 10) | (uint32_t(p[1]) << 2) | (p[2] >> 6);
                 const bool utc_long = (p[2] >> 3) & 1;
                 ens.hours = ((p[2] & 7) << 2) | (p[3] >> 6);

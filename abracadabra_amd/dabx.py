@@ -14,7 +14,8 @@ CIF_SOFT_BITS = 55296
 MSC_STRIDE = 6912
 
 SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("peak_idx", "<i4"),
-                       ("m_int", "<i4"), ("peak", "<f4"), ("total", "<f4"), ("cp_re", "<i8"), ("cp_im", "<i8")])
+                       ("m_int", "<i4"), ("peak", "<f4"), ("total", "<f4"), ("cp_re", "<i8"), ("cp_im", "<i8"),
+                       ("e_null", "<i8"), ("e_sig", "<i8")])
 
 # every symbol include/dabx.h declares; tests check that the library exports them all
 DABX_SYMBOLS = [

@@ -65,6 +65,7 @@ typedef struct {
     int32_t m_int;                /* integer carrier offset found by the wide search      */
     float   peak, total;          /* |h|^2 peak and sum                                   */
     int64_t cp_re, cp_im;         /* guard-interval correlation                           */
+    int64_t e_null, e_sig;        /* energy of 2048 samples inside the null symbol / PRS  */
 } dabx_sync_rec_t;
 
 typedef struct {

@@ -65,8 +65,9 @@ class Profile(C.Structure):
 
 
 SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("peak_idx", "<i4"),
-                       ("m_int", "<i4"), ("peak", "<f4"), ("total", "<f4"), ("cp_re", "<i8"), ("cp_im", "<i8")])
-assert SYNC_DTYPE.itemsize == 48
+                       ("m_int", "<i4"), ("peak", "<f4"), ("total", "<f4"), ("cp_re", "<i8"), ("cp_im", "<i8"),
+                       ("e_null", "<i8"), ("e_sig", "<i8")])
+assert SYNC_DTYPE.itemsize == 64
 
 
 def eep_profile(option, level, kbps):

@@ -236,6 +236,7 @@ typedef struct {                /* per-frame synchronisation record (same layout
     int32_t peak_idx, m_int;
     float peak, total;
     int64_t cp_re, cp_im;
+    int64_t e_null, e_sig;      /* sample energy over 2048 samples of the null symbol / of the PRS */
 } orx_sync_t;
 
 orx_t *orx_create(int fmt, int64_t ring_len, int ti_slots)
@@ -361,6 +362,12 @@ static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, or
             cim += (int64_t)q1 * i2 - (int64_t)i1 * q2;
         }
     }
+    int64_t e_null = 0, e_sig = 0;
+    for (int n = 0; n < DAB_TU; n++) {
+        int32_t i, q;
+        sample(s, pos_f + 128 + n, &i, &q); e_null += (int64_t)i * i + (int64_t)q * q;
+        sample(s, pos_f + DAB_TNULL + DAB_TG + n, &i, &q); e_sig += (int64_t)i * i + (int64_t)q * q;
+    }
     int32_t A = orx_cordic(cim, cre);
     int32_t inc_meas = (int32_t)((-(int64_t)A) >> 11);   /* |.| <= 2^20 */
     int32_t inc;
@@ -434,6 +441,7 @@ static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, or
     rec->peak_idx = pidx; rec->m_int = m_best;
     rec->peak = peak; rec->total = total;
     rec->cp_re = cre; rec->cp_im = cim;
+    rec->e_null = e_null; rec->e_sig = e_sig;
 }
 
 /* demodulate the 76 symbols of one frame: FIC soft bits to fic[9216], MSC soft

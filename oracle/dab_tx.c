@@ -108,6 +108,14 @@ static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *f
         fig_t *f = &figs[n++];
         f->b[0] = 0x04; f->b[1] = 0x09; f->b[2] = 0x02; f->b[3] = 0xE2; f->b[4] = 0x01; f->len = 5;
     }
+    { /* FIG 0/10 date and time, long form: MJD 60587 (2024-10-04), 12:34:56.789 UTC */
+        fig_t *f = &figs[n++];
+        const unsigned mjd = 60587, hh = 12, mm = 34, ss = 56, ms = 789;
+        const unsigned w = (mjd << 14) | (0u << 13) | (1u << 12) | (1u << 11) | (hh << 6) | mm;
+        f->b[0] = 0x07; f->b[1] = 0x0A;
+        f->b[2] = (uint8_t)(w >> 24); f->b[3] = (uint8_t)(w >> 16); f->b[4] = (uint8_t)(w >> 8); f->b[5] = (uint8_t)w;
+        f->b[6] = (uint8_t)((ss << 2) | (ms >> 8)); f->b[7] = (uint8_t)ms; f->len = 8;
+    }
     { /* FIG 1/0 ensemble label */
         fig_t *f = &figs[n++];
         char lab[17];

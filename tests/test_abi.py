@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_reference_abi():
     # sizeof(dabsdrNtfPeriodic_t) is asserted to be the notification length by the host (radiocontrol.cpp:2407)
-    assert dabx.SYNC_DTYPE.itemsize == 48 and C.sizeof(dabx.StreamState) == 40 and C.sizeof(dabx.Config) == 24
+    assert dabx.SYNC_DTYPE.itemsize == 64 and C.sizeof(dabx.StreamState) == 40 and C.sizeof(dabx.Config) == 24
     L = aa.load_library()
     ver = (C.c_uint8 * 4)()
     L.dabsdrGetVersion(ver)
@@ -56,7 +56,7 @@ def test_fig_database_reads_transmitted_fibs():
     n = L.dabsdr_amd_fig_dump(flat.ctypes.data, len(flat), buf, 8192)
     text = buf.value.decode()
     assert n > 0
-    assert "eid=10AB ecc=E2 lto=2" in text and "GRAFT ENS" in text
+    assert "eid=10AB ecc=E2 lto=2" in text and "GRAFT ENS" in text and "utc=60587 12:34:56.789" in text
     assert "subch id=0 start=0 size=48 opt=0 level=3 kbps=64" in text
     assert "subch id=1 start=48 size=15 opt=1 level=4 kbps=32" in text
     assert "subch id=2 start=100 size=58 opt=0 level=2 kbps=64" in text          # UEP index 17 via the short form

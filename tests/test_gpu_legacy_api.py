@@ -75,12 +75,13 @@ def test_tune_lock_ensemble_and_service_list():
             rec["freq"] = C.cast(n.pData, C.POINTER(C.c_uint32)).contents.value
         elif n.nid == NID["SYNC_STATUS"]:
             rec["level"] = C.cast(n.pData, C.POINTER(C.c_int)).contents.value
+            rec["snr10"] = C.cast(n.pData + 4, C.POINTER(C.c_int16)).contents.value
         elif n.nid == NID["ENSEMBLE_INFO"]:
             e = C.cast(n.pData, C.POINTER(Ensemble)).contents
             rec.update(ueid=e.ueid, lto=e.LTO, label=e.label.str.decode(), freq=e.frequency)
         elif n.nid == NID["PERIODIC"] and n.pData:
             pr = C.cast(n.pData, C.POINTER(Periodic)).contents
-            rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel)
+            rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel, dhm=pr.dateHoursMinutes, secms=pr.secMsec)
         elif n.nid == NID["SERVICE_LIST"]:
             sl = C.cast(n.pData, C.POINTER(ServiceList)).contents
             items = []
@@ -120,9 +121,14 @@ def test_tune_lock_ensemble_and_service_list():
 
     wait_for(lambda e: e["nid"] == NID["TUNE"] and e.get("freq") == 225648)
     wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)       # DABSDR_SYNC_LEVEL_FIC
+    fic = wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)[-1]
+    assert 200 <= fic["snr10"] <= 300                                                 # signal generated at 25 dB
     per = wait_for(lambda e: e["nid"] == NID["PERIODIC"] and "fib_err" in e and e["level"] == 3)
     assert per[-1]["fib_err"] == 0
     assert abs(per[-1]["foff"] / 10.0 - cfo) < 10.0                                   # Hz, positive = above nominal
+    dated = wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e.get("dhm"))[-1]        # FIG 0/10 as the host decodes it
+    assert (dated["dhm"] >> 14) & 0x1FFFF == 60587 and (dated["dhm"] >> 6) & 0x1F == 12 and dated["dhm"] & 0x3F == 34   # dabtables.cpp:128-134
+    assert dated["secms"] >> 10 == 56 and dated["secms"] & 0x3FF == 789
     time.sleep(0.3)
     L.dabsdrRequest_GetEnsemble(handle)
     ens = wait_for(lambda e: e["nid"] == NID["ENSEMBLE_INFO"] and e["status"] == 0)[-1]
