@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--snr", type=float, default=20.0)
     ap.add_argument("--nsub", type=int, default=18, help="48-CU EEP 3-A sub-channels per ensemble (18 = all 864 CU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); gloo only for rehearsals")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--cpu-frames", type=int, default=208)
     return ap.parse_args()
 
@@ -108,9 +110,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
-    torch.cuda.set_device(local_rank)
+    dev = args.force_device if args.force_device >= 0 else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
 
     import abracadabra_amd as aa
     from oracle import binding as ob
@@ -123,7 +129,7 @@ def main():
         streams = list(ex.map(lambda s: make_stream(args, rank, s, sub), range(S)))
     t_gen = time.perf_counter() - t_gen
 
-    ctx = aa.Context(n_streams=S, fmt=0, ring_frames=P, max_frames=F, device=local_rank)
+    ctx = aa.Context(n_streams=S, fmt=0, ring_frames=P, max_frames=F, device=dev)
     for s, (iq, _, _, _) in enumerate(streams):
         ctx.set_subchannels(s, sub)
         ctx.push(s, iq)                          # fills the ring exactly once: the signal is periodic
@@ -166,7 +172,8 @@ def main():
                     checked += 1
                     mism += (gm[f, c].tobytes() not in msc_set)
 
-    t = torch.tensor([elapsed, float(ok), float(bad), float(mism)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, float(ok), float(bad), float(mism)], dtype=torch.float64,
+                     device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -186,7 +193,7 @@ def main():
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 FFT / int8 soft bits / int32 path metrics", "data": "synthetic",
-            "config": {"workload": "configs[3]: 256 concurrent synthetic Mode-I ensembles per GPU, full FIC + MSC (18 x 48 CU EEP 3-A) Viterbi",
+            "config": {"workload": f"configs[3]: {S} concurrent synthetic Mode-I ensembles per GPU, full FIC + MSC ({args.nsub} x 48 CU EEP 3-A) Viterbi",
                        "streams_per_gpu": S, "frames_per_step": F, "snr_db": args.snr, "sample_format": "u8 IQ 2.048 Msps",
                        "parallelism": f"{world} x independent streams, no data-path collective"},
             "msym_per_s": round(value / FRAME_S * SYMS_PER_FRAME / 1e6, 3),

@@ -209,3 +209,29 @@ def test_config2_64_streams_fft_demap_bit_exact(gpu_ctx_factory):
         bad += int((~gok.astype(bool)).sum())
         assert np.array_equal(gf, fib[:1])
     assert bad == 0
+
+
+def test_lock_loss_and_reacquisition_matches_oracle(gpu_ctx_factory):
+    from test_oracle_chain import _gap_signal
+    sub, iq, fib_a, fib_b = _gap_signal()
+    ctx = gpu_ctx_factory(n_streams=1, fmt=0, ring_frames=32, max_frames=2)
+    ctx.set_subchannels(0, sub)
+    ctx.push(0, iq)
+    orc = ob.Stream(subch=sub, ring_len=ctx.ring_samples)
+    orc.push(iq)
+    locked = []
+    for step in range(9):
+        if ctx.frames_available() < 2:
+            break
+        ctx.process(2)
+        o = orc.process(2)
+        assert o["rc"] in (0, 2)
+        assert np.array_equal(ctx.sync(0), o["sync"]), step
+        gf, gok = ctx.fib(0)
+        assert np.array_equal(gok, o["fib_ok"])
+        if o["rc"]:
+            assert np.array_equal(gf, o["fib"])
+        st, so = ctx.state(0), orc.state()
+        assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"])
+        locked.append(st["locked"])
+    assert locked[0] == 1 and 0 in locked[1:] and locked[-1] == 1

@@ -71,3 +71,32 @@ def test_uep_subchannels_roundtrip():
     got = o["msc"].reshape(20, -1)
     for c in range(15, 20):
         assert np.array_equal(got[c], msc[c - 15])
+
+
+def _gap_signal():
+    """6 good frames, 5 frames of noise, then a second transmission with another timing/offset"""
+    sub = ob.subch_layout(2, 64)
+    a, fib_a, _ = ob.tx_generate(seed=21, n_frames=6, subch=sub, delay=1000, snr_db=20.0, cfo_hz=900.0)
+    rng = np.random.default_rng(4)
+    gap = rng.integers(118, 139, 2 * 5 * ob.TF, dtype=np.uint8)
+    b, fib_b, _ = ob.tx_generate(seed=22, eid=0x2222, n_frames=9, subch=sub, delay=77777, snr_db=20.0, cfo_hz=-3100.0)
+    return sub, np.concatenate([a, gap, b]), fib_a, fib_b
+
+
+def test_lock_loss_and_reacquisition():
+    sub, iq, fib_a, fib_b = _gap_signal()
+    s = ob.Stream(subch=sub, ring_len=32 * ob.TF)
+    s.push(iq)
+    seen, locked = [], []
+    for _ in range(9):
+        o = s.process(2)
+        if o["rc"] < 0:
+            break
+        seen.append(o)
+        locked.append(s.state()["locked"])
+    assert locked[0] == 1 and 0 in locked[1:] and locked[-1] == 1          # lock, loss in the gap, lock again
+    assert np.array_equal(seen[0]["fib"], fib_a[:2]) and seen[0]["fib_ok"].all()
+    last = seen[-1]
+    assert last["fib_ok"].all()
+    tx_b = {f.tobytes() for f in fib_b}
+    assert all(f.tobytes() in tx_b for f in last["fib"])                    # decoding the second transmission
