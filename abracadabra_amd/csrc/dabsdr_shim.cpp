@@ -12,6 +12,7 @@
 #include "../../include/dabx.h"
 #include "fig_db.hpp"
 #include "superframe.hpp"
+#include "tii.hpp"
 
 #include <pthread.h>
 
@@ -72,8 +73,10 @@ struct dabsdr_s {
     dabplus::Decoder aac;                 // DAB+ super frame -> access units
     dabplus::Stats last_stats;
     uint32_t audio_bytes_acc = 0;
-    bool spectrum_on = false;
-    std::vector<float> spectrum;
+    bool spectrum_on = false, tii_on = false;
+    int tii_mode = DABSDR_TII_MODE_DEFAULT;
+    std::vector<float> spectrum, null_power;
+    float tii_folded[384] = {0};
     std::vector<figdb::Service> list_snapshot;       // for the list getters (valid during a callback)
     std::vector<figdb::Component> comp_snapshot;
     uint32_t comp_sid = 0;
@@ -175,7 +178,7 @@ void handle_request(dabsdr_s *h, const Request &r)
                 dabx_destroy(h->ctx);
                 h->ctx = nullptr;
                 if (dabx_create(&cfg, &h->ctx) != DABX_OK) h->ctx = nullptr;
-                else if (h->spectrum_on) dabx_enable_spectrum(h->ctx, 1);
+                else dabx_enable_spectrum(h->ctx, (h->spectrum_on ? 1 : 0) | 2);
             }
             uint32_t f = r.a;
             notify(h, DABSDR_NID_TUNE, h->ctx ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_GENERIC_ERROR, &f, 0);
@@ -278,9 +281,13 @@ void handle_request(dabsdr_s *h, const Request &r)
         break;
     case Req::SignalSpectrum:
         h->spectrum_on = r.a != 0;
-        if (h->ctx) dabx_enable_spectrum(h->ctx, h->spectrum_on ? 1 : 0);
+        if (h->ctx) dabx_enable_spectrum(h->ctx, (h->spectrum_on ? 1 : 0) | 2);
         break;
-    case Req::SetTII:                     // TII detection: not implemented yet
+    case Req::SetTII:
+        h->tii_on = r.a != 0;
+        h->tii_mode = r.b;
+        if (h->ctx) dabx_enable_spectrum(h->ctx, (h->spectrum_on ? 1 : 0) | 2);
+        break;
     case Req::Exit:
         break;
     }
@@ -319,11 +326,27 @@ void after_step(dabsdr_s *h)
     for (int i = 0; i < 12; ++i)
         if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
     const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
-    // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy
+    // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy.
+    // The null symbol may carry TII carriers (32 of 1536), so its noise level is taken from the median
+    // in-band bin of its spectrum (median of an exponential distribution = mean * ln 2) rather than
+    // from its total energy; for a TII-free null the two agree.
+    bool have_null = false;
+    double noise = static_cast<double>(rec.e_null);
+    if (st.locked) {
+        h->null_power.resize(2048);
+        have_null = dabx_get_null_spectrum(h->ctx, 0, h->null_power.data()) == DABX_OK;
+        if (have_null) {
+            float band[1536];
+            std::memcpy(band, h->null_power.data() + 1, 768 * sizeof(float));
+            std::memcpy(band + 768, h->null_power.data() + 2048 - 768, 768 * sizeof(float));
+            std::nth_element(band, band + 768, band + 1536);
+            noise = static_cast<double>(band[768]) / 0.6931471805599453;
+        }
+    }
     int16_t snr10 = 0;
-    if (rec.e_null > 0 && rec.e_sig > rec.e_null)
-        snr10 = static_cast<int16_t>(std::lround(100.0 * std::log10(static_cast<double>(rec.e_sig - rec.e_null) / static_cast<double>(rec.e_null))));
-    else if (rec.e_sig > 0 && rec.e_null == 0) snr10 = 600;
+    const double sig = static_cast<double>(rec.e_sig);
+    if (noise > 0 && sig > noise) snr10 = static_cast<int16_t>(std::min(600L, std::lround(100.0 * std::log10((sig - noise) / noise))));
+    else if (sig > 0 && noise <= 0) snr10 = 600;
     if (lvl != h->sync_level) {
         h->sync_level = lvl;
         dabsdrNtfSyncStatus_t s = {lvl, snr10};
@@ -333,6 +356,22 @@ void after_step(dabsdr_s *h)
     if (h->spectrum_on && h->spec_cb) {
         h->spectrum.resize(2048);
         if (dabx_get_spectrum(h->ctx, 0, h->spectrum.data()) == DABX_OK) h->spec_cb(h->spectrum.data(), DABSDR_SPECT_SIGNAL, h->spec_ctx);
+    }
+    if ((h->tii_on || h->spectrum_on) && st.locked) {
+        if (have_null) {
+            if (h->spectrum_on && h->spec_cb) h->spec_cb(h->null_power.data(), DABSDR_SPECT_NULL, h->spec_ctx);
+            if (h->tii_on) {
+                const auto ids = tii::detect(h->null_power.data(), h->tii_mode == DABSDR_TII_MODE_CONSERVATIVE ? 8.0f : 4.0f);
+                tii::fold(h->null_power.data(), h->tii_folded);
+                dabsdrNtfTii_t n;
+                std::memset(&n, 0, sizeof n);
+                n.numIds = static_cast<uint8_t>(ids.size());
+                for (size_t i = 0; i < ids.size(); ++i) n.id[i] = {ids[i].main, ids[i].sub, ids[i].level};
+                // the header declares float[192] but the host passes 384 floats (radiocontrol.h:280)
+                n.getSpectrumTii = [](dabsdrHandle_t hh, float *b) { std::memcpy(b, hh->tii_folded, sizeof hh->tii_folded); return 0; };
+                notify(h, DABSDR_NID_TII, DABSDR_NSTAT_SUCCESS, &n, sizeof n);
+            }
+        }
     }
     // selected audio service: the CIF's decoded sub-channel bytes -> access units -> audio callback
     if (h->sel_active && h->audio_cb && h->sel_kbps > 0) {
@@ -447,6 +486,7 @@ uint8_t dabsdrInit(dabsdrHandle_t *handle)
         *handle = nullptr;
         return EXIT_FAILURE;
     }
+    dabx_enable_spectrum(h->ctx, 2);                 // null-symbol spectrum: noise estimate and TII
     *handle = h;
     return EXIT_SUCCESS;
 }
@@ -502,6 +542,18 @@ void dabsdrRequest_Exit(dabsdrHandle_t h)
     if (!h) return;
     h->exit_req.store(true);
     post(h, {Req::Exit, 0, 0, 0});
+}
+
+// test hook (CPU only): TII detection on a 2048-bin null-symbol power spectrum; ids = {main, sub} pairs
+DABSDR_API int dabsdr_amd_tii_detect(const float *power, float factor, uint8_t *ids, int max_ids)
+{
+    const auto v = tii::detect(power, factor);
+    int n = 0;
+    for (const auto &id : v) {
+        if (n >= max_ids) break;
+        ids[2 * n] = id.main; ids[2 * n + 1] = id.sub; ++n;
+    }
+    return n;
 }
 
 // test hook (CPU only): run logical frames of a DAB+ sub-channel through the super frame decoder.

@@ -84,7 +84,7 @@ struct dabx_ctx {
     int16_t *d_bop = nullptr, *d_nob = nullptr, *d_car = nullptr;
     int8_t *d_pq = nullptr, *d_pdq = nullptr;
     int32_t *d_cordic = nullptr;
-    float *d_spectrum = nullptr;            // optional, dabx_enable_spectrum
+    float *d_spectrum = nullptr, *d_null_spectrum = nullptr;   // optional, dabx_enable_spectrum
     DevState *h_state = nullptr;            // pinned mirror
 
     std::vector<StreamHost> streams;
@@ -103,7 +103,7 @@ struct dabx_ctx {
         c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car, d_cordic};
         c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
         c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
-        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.spectrum = d_spectrum;
+        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
         c.ring_len = cfg.ring_samples; c.ring_bytes = static_cast<size_t>(cfg.ring_samples) * bps;
         c.n_streams = cfg.n_streams; c.max_frames = cfg.max_frames; c.ti_slots = ti_slots;
         c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0;
@@ -328,7 +328,7 @@ void dabx_destroy(dabx_ctx *c)
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
-                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_groups, c->d_gcw, c->d_blk_group, c->d_blk_index, c->d_xbuf, c->d_decbuf, c->d_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_groups, c->d_gcw, c->d_blk_group, c->d_blk_index, c->d_xbuf, c->d_decbuf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -609,18 +609,22 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     return p.n_in / 8;
 }
 
-int dabx_enable_spectrum(dabx_ctx *c, int on)
+int dabx_enable_spectrum(dabx_ctx *c, int mask)
 {
     if (!c) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->pending) return DABX_E_ARG;
-    if (on && !c->d_spectrum) {
-        const size_t bytes = static_cast<size_t>(c->cfg.n_streams) * 2048 * sizeof(float);
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_spectrum), bytes));
-        HIPCHK(hipMemset(c->d_spectrum, 0, bytes));
-    } else if (!on && c->d_spectrum) {
-        (void)hipFree(c->d_spectrum);
-        c->d_spectrum = nullptr;
+    const size_t bytes = static_cast<size_t>(c->cfg.n_streams) * 2048 * sizeof(float);
+    float **bufs[2] = {&c->d_spectrum, &c->d_null_spectrum};
+    for (int k = 0; k < 2; ++k) {
+        const bool want = (mask >> k) & 1;
+        if (want && !*bufs[k]) {
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(bufs[k]), bytes));
+            HIPCHK(hipMemset(*bufs[k], 0, bytes));
+        } else if (!want && *bufs[k]) {
+            (void)hipFree(*bufs[k]);
+            *bufs[k] = nullptr;
+        }
     }
     return DABX_OK;
 }
@@ -630,6 +634,14 @@ int dabx_get_spectrum(dabx_ctx *c, int s, float *power)
     GETTER_PROLOGUE
     if (!power || !c->d_spectrum) return DABX_E_ARG;
     HIPCHK(hipMemcpy(power, c->d_spectrum + static_cast<size_t>(s) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_null_spectrum(dabx_ctx *c, int s, float *power)
+{
+    GETTER_PROLOGUE
+    if (!power || !c->d_null_spectrum) return DABX_E_ARG;
+    HIPCHK(hipMemcpy(power, c->d_null_spectrum + static_cast<size_t>(s) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
     return DABX_OK;
 }
 

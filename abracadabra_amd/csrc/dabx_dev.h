@@ -75,6 +75,7 @@ struct DevCtx {
     const uint32_t *prbs;       // energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
     uint32_t *dec_scratch;      // decision words of codewords too long for LDS
     float *spectrum;            // [S][2048] |FFT|^2 of the last frame's PRS window, natural bin order; may be null
+    float *null_spectrum;       // [S][2048] same for 2048 samples in the middle of the null symbol (TII); may be null
     int64_t ring_len;           // samples
     size_t ring_bytes;          // bytes per stream
     int32_t n_streams, max_frames, ti_slots, msc_stride, fic_info_off;

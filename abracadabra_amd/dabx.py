@@ -22,7 +22,7 @@ DABX_SYMBOLS = [
     "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_ring_ptr",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
-    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum",
+    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum",
 ]
 
 
@@ -221,9 +221,16 @@ class Context:
         nb = _chk(self.L.dabx_viterbi(self.h, kind, option, level, kbps, soft.ctypes.data, n_cw, flat.ctypes.data))
         return flat[:n_cw * nb].reshape(n_cw, nb).copy()
 
-    def enable_spectrum(self, on=True):
+    def enable_spectrum(self, mask=1):
+        """mask bit 0: PRS (signal) spectrum, bit 1: null-symbol spectrum"""
         self.L.dabx_enable_spectrum.argtypes = [C.c_void_p, C.c_int]
-        _chk(self.L.dabx_enable_spectrum(self.h, 1 if on else 0))
+        _chk(self.L.dabx_enable_spectrum(self.h, int(mask)))
+
+    def null_spectrum(self, stream):
+        p = np.zeros(2048, dtype=np.float32)
+        self.L.dabx_get_null_spectrum.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _chk(self.L.dabx_get_null_spectrum(self.h, stream, p.ctypes.data))
+        return p
 
     def spectrum(self, stream):
         p = np.zeros(2048, dtype=np.float32)

@@ -145,11 +145,14 @@ DABX_API int dabx_fft2048(dabx_ctx *ctx, const float *in, float *out, int n_vec)
 DABX_API int dabx_viterbi(dabx_ctx *ctx, int kind, int option, int level, int kbps,
                           const int8_t *soft, int n_cw, uint8_t *out);
 
-/* Signal spectrum of the last decoded frame: 2048 bins of linear power of the un-normalised FFT of
- * the phase-reference symbol, natural order (bin 0 = DC, 1024.. = negative frequencies) — the
- * payload of the reference's spectrum callback (dabsdr.h:393; consumer src/signalbackend.cpp:383-429). */
-DABX_API int dabx_enable_spectrum(dabx_ctx *ctx, int on);
+/* Spectra of the last decoded frame, 2048 bins of linear power of the un-normalised FFT in natural
+ * order (bin 0 = DC, 1024.. = negative frequencies): the payload of the reference's spectrum
+ * callback (dabsdr.h:365-370, :393; consumer src/signalbackend.cpp:383-429).
+ *   mask bit 0: phase-reference symbol (DABSDR_SPECT_SIGNAL)
+ *   mask bit 1: null symbol (DABSDR_SPECT_NULL; input of the TII detector, dabsdr.h:372-384) */
+DABX_API int dabx_enable_spectrum(dabx_ctx *ctx, int mask);
 DABX_API int dabx_get_spectrum(dabx_ctx *ctx, int stream, float *power);
+DABX_API int dabx_get_null_spectrum(dabx_ctx *ctx, int stream, float *power);
 
 /* Raw-file front end: the reference's RawFileInput accepts headerless `.raw` files and `.uff`
  * files whose first 2048 bytes hold a zero-padded XML description (reference:

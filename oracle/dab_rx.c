@@ -227,6 +227,7 @@ typedef struct {
     int ti_slots;               /* power of two */
     uint32_t fic_stepinfo[DAB_FIC_CW_IN + 6];
     float spectrum[NFFT];       /* |FFT|^2 of the last frame's PRS window, natural bin order */
+    float null_spectrum[NFFT];  /* same for 2048 samples centred in the null symbol */
 } orx_t;
 
 typedef struct {                /* per-frame synchronisation record (same layout as dabx_sync_rec) */
@@ -285,6 +286,7 @@ void orx_push(orx_t *s, const void *iq, int64_t n)
     s->wr += n;
 }
 void orx_get_spectrum(const orx_t *s, float *out) { memcpy(out, s->spectrum, sizeof s->spectrum); }
+void orx_get_null_spectrum(const orx_t *s, float *out) { memcpy(out, s->null_spectrum, sizeof s->null_spectrum); }
 void orx_get_state(const orx_t *s, int64_t *st)
 {
     st[0] = s->pos; st[1] = s->inc; st[2] = s->locked; st[3] = s->cif; st[4] = s->bad; st[5] = s->wr;
@@ -349,7 +351,7 @@ static void load_window(const orx_t *s, int64_t w0, int64_t ref, int32_t inc, fl
     }
 }
 
-static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec, float *spectrum)
+static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec, float *spectrum, float *null_spectrum)
 {
     /* 1. guard-interval correlation over PRS + 3 FIC symbols (exact integers) */
     int64_t cre = 0, cim = 0;
@@ -442,6 +444,15 @@ static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, or
     rec->peak = peak; rec->total = total;
     rec->cp_re = cre; rec->cp_im = cim;
     rec->e_null = e_null; rec->e_sig = e_sig;
+    if (null_spectrum) {
+        int64_t n0 = pos_f + (DAB_TNULL - DAB_TU) / 2;
+        load_window(s, n0, n0, inc, xr, xi);
+        fft_pos(xr, xi);
+        for (int p = 0; p < NFFT; p++) {
+            float a = xr[p] * xr[p], b = xi[p] * xi[p];
+            null_spectrum[T.bin_of_pos[p]] = a + b;
+        }
+    }
 }
 
 /* demodulate the 76 symbols of one frame: FIC soft bits to fic[9216], MSC soft
@@ -594,7 +605,7 @@ int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8
     orx_sync_t rec;
     int nbad = s->bad;
     for (int f = 0; f < n_frames; f++) {
-        sync_frame(s, s->pos + (int64_t)f * DAB_TF, s->inc, wide, &rec, f == n_frames - 1 ? s->spectrum : NULL);
+        sync_frame(s, s->pos + (int64_t)f * DAB_TF, s->inc, wide, &rec, f == n_frames - 1 ? s->spectrum : NULL, f == n_frames - 1 ? s->null_spectrum : NULL);
         if (sync) sync[f] = rec;
         int64_t cif0 = s->cif + 4 * (int64_t)f;
         demod_frame(s, &rec, cif0, ficbuf);

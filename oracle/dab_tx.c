@@ -26,6 +26,7 @@ typedef struct {
     double   rms;          /* complex RMS of the signal in LSB         */
     int32_t  subch[64][4]; /* {start_cu, option(0=A,1=B,2=UEP), level, kbps} */
     int32_t  payload_given;/* 1: msc_out already holds the payload to transmit    */
+    int32_t  tii_main, tii_sub; /* TII in every null symbol (EN 300 401 §14.8); main < 0: none */
 } dab_tx_cfg_t;
 
 /* ---- deterministic PRNG (splitmix64) ---- */
@@ -261,6 +262,26 @@ int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *
         size_t len = (f < 0) ? (size_t)c->delay : DAB_TF;
         if (len == 0) continue;
         memset(frame, 0, sizeof(double) * 2 * len);
+        if (f >= 0 && c->tii_main >= 0) {
+            /* TII: carrier pairs k, k+1 with k = base + 2c + 48b carry the PRS phase of carrier k */
+            static const int base[4] = {-768, -384, 1, 385};
+            int word = -1, cnt = 0;
+            for (int w = 0; w < 256 && word < 0; w++)
+                if (__builtin_popcount(w) == 4 && cnt++ == c->tii_main) word = w;
+            for (int b = 0; b < DAB_TU; b++) re[b] = im[b] = 0.0;
+            for (int blk = 0; blk < 4 && word >= 0; blk++)
+                for (int b = 0; b < 8; b++) {
+                    if (!(word & (0x80 >> b))) continue;
+                    int k = base[blk] + 2 * c->tii_sub + 48 * b, q = prsq[k & 2047];
+                    static const double cq[4] = {1, 0, -1, 0};
+                    for (int d = 0; d < 2; d++) { re[(k + d) & 2047] = cq[q & 3]; im[(k + d) & 2047] = cq[(q + 3) & 3]; }
+                }
+            ifft2048(re, im, tw);
+            for (int n = 0; n < DAB_TNULL; n++) {
+                int src = (n + DAB_TU - (DAB_TNULL - DAB_TU)) & (DAB_TU - 1);
+                frame[2 * n] = re[src] * amp / DAB_TU; frame[2 * n + 1] = im[src] * amp / DAB_TU;
+            }
+        }
         if (f >= 0) {
             for (int b = 0; b < DAB_TU; b++) ph8[b] = (uint8_t)(prsq[b] < 0 ? 0 : 2 * prsq[b]);
             for (int l = 0; l < DAB_NSYM; l++) {

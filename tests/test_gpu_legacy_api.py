@@ -14,7 +14,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 NID = dict(SYNC_STATUS=1, TUNE=2, ENSEMBLE_INFO=3, SERVICE_LIST=4, SERVICE_COMPONENT_LIST=5, SERVICE_SELECTION=8,
-           PERIODIC=10, RESET=13)
+           PERIODIC=10, RESET=13, TII=17)
 
 
 class Label(C.Structure):
@@ -41,6 +41,14 @@ class Ntf(C.Structure):
     _fields_ = [("nid", C.c_int), ("status", C.c_int), ("len", C.c_uint16), ("pData", C.c_void_p)]
 
 
+class TiiId(C.Structure):
+    _fields_ = [("main", C.c_uint8), ("sub", C.c_uint8), ("level", C.c_float)]
+
+
+class NtfTii(C.Structure):
+    _fields_ = [("numIds", C.c_uint8), ("id", TiiId * 24), ("getSpectrumTii", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float)))]
+
+
 class ServiceList(C.Structure):
     _fields_ = [("numServices", C.c_uint8), ("getItem", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint8, C.POINTER(ServiceItem)))]
 
@@ -53,7 +61,7 @@ def test_tune_lock_ensemble_and_service_list():
     L = aa.load_library()
     cfo = 1500.0
     sub = [[0, 0, 3, 64], [48, 1, 4, 32]]
-    iq, fib, _ = ob.tx_generate(seed=77, eid=0x1234, n_frames=24, subch=sub, delay=5000, snr_db=25.0, cfo_hz=cfo)
+    iq, fib, _ = ob.tx_generate(seed=77, eid=0x1234, n_frames=24, subch=sub, delay=5000, snr_db=25.0, cfo_hz=cfo, tii=(21, 5))
     samples = (iq.astype(np.float32) - 128.0)              # what RawFileWorker produces (rawfileinput.cpp:692)
     pos = [0]
     events, lock = [], threading.Lock()
@@ -82,6 +90,11 @@ def test_tune_lock_ensemble_and_service_list():
         elif n.nid == NID["PERIODIC"] and n.pData:
             pr = C.cast(n.pData, C.POINTER(Periodic)).contents
             rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel, dhm=pr.dateHoursMinutes, secms=pr.secMsec)
+        elif n.nid == NID["TII"]:
+            t = C.cast(n.pData, C.POINTER(NtfTii)).contents
+            spec = (C.c_float * 384)()                       # the host's buffer size (radiocontrol.h:280)
+            t.getSpectrumTii(handle, spec)
+            rec.update(ids=[(t.id[i].main, t.id[i].sub) for i in range(t.numIds)], spec=np.array(spec))
         elif n.nid == NID["SERVICE_LIST"]:
             sl = C.cast(n.pData, C.POINTER(ServiceList)).contents
             items = []
@@ -107,6 +120,8 @@ def test_tune_lock_ensemble_and_service_list():
     L.dabsdrRequest_SetPeriodicNotify.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32]
     L.dabsdr(handle)
     L.dabsdrRequest_SetPeriodicNotify(handle, 1, 0)          # every 2 frames
+    L.dabsdrRequest_SetTII.argtypes = [C.c_void_p, C.c_uint8, C.c_int]
+    L.dabsdrRequest_SetTII(handle, 1, 1)
     L.dabsdrRequest_Tune(handle, 225648)
 
     def wait_for(pred, timeout=60.0):
@@ -129,6 +144,9 @@ def test_tune_lock_ensemble_and_service_list():
     dated = wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e.get("dhm"))[-1]        # FIG 0/10 as the host decodes it
     assert (dated["dhm"] >> 14) & 0x1FFFF == 60587 and (dated["dhm"] >> 6) & 0x1F == 12 and dated["dhm"] & 0x3F == 34   # dabtables.cpp:128-134
     assert dated["secms"] >> 10 == 56 and dated["secms"] & 0x3FF == 789
+    tii = wait_for(lambda e: e["nid"] == NID["TII"] and e.get("ids"))[-1]
+    assert tii["ids"] == [(21, 5)]                                                    # transmitter pattern 21, comb 5
+    assert tii["spec"].shape == (384,) and tii["spec"].max() > 20 * np.median(tii["spec"])
     time.sleep(0.3)
     L.dabsdrRequest_GetEnsemble(handle)
     ens = wait_for(lambda e: e["nid"] == NID["ENSEMBLE_INFO"] and e["status"] == 0)[-1]

@@ -181,6 +181,26 @@ def test_signal_spectrum_matches_oracle(gpu_ctx_factory):
     assert g[band].mean() > 50 * g[800:1248].mean()                          # 1536 carriers stand out of the guard band
 
 
+def test_null_spectrum_matches_oracle_and_carries_tii(gpu_ctx_factory):
+    import ctypes as C
+    sub = ob.subch_layout(2, 64)
+    iq, _, _ = ob.tx_generate(seed=71, n_frames=4, subch=sub, delay=800, snr_db=15.0, cfo_hz=-1800.0, tii=(52, 7))
+    ctx = gpu_ctx_factory(n_streams=1, fmt=0, ring_frames=8, max_frames=2)
+    ctx.enable_spectrum(3)
+    ctx.push(0, iq)
+    ctx.process(2)
+    orc = ob.Stream(ring_len=8 * ob.TF)
+    orc.push(iq)
+    orc.process(2)
+    g, o = ctx.null_spectrum(0), orc.null_spectrum()
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))              # bit for bit
+    assert np.array_equal(ctx.spectrum(0).view(np.uint32), orc.spectrum().view(np.uint32))
+    ids = np.zeros(48, dtype=np.uint8)
+    ctx.L.dabsdr_amd_tii_detect.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int]
+    n = ctx.L.dabsdr_amd_tii_detect(g.ctypes.data, 4.0, ids.ctypes.data, 24)
+    assert n == 1 and tuple(ids[:2]) == (52, 7)
+
+
 def test_config2_64_streams_fft_demap_bit_exact(gpu_ctx_factory):
     """BASELINE configs[1]: 64 synthetic Mode-I IQ streams batched through sync + 2048-FFT + DQPSK
     demap; every soft bit equals the oracle's, and at 25 dB the hard decisions of the FIC symbols

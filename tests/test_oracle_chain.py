@@ -100,3 +100,21 @@ def test_lock_loss_and_reacquisition():
     assert last["fib_ok"].all()
     tx_b = {f.tobytes() for f in fib_b}
     assert all(f.tobytes() in tx_b for f in last["fib"])                    # decoding the second transmission
+
+
+def test_tii_in_null_symbol_is_detected():
+    """TX places TII (EN 300 401 14.8) in the null symbol; the oracle's null spectrum through the product's
+    host-side detector returns the transmitter, and stays silent without TII."""
+    import ctypes as C
+    import abracadabra_amd as aa
+    L = aa.load_library()
+    L.dabsdr_amd_tii_detect.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int]
+    for tii in [(0, 0), (69, 23), (37, 11), None]:
+        iq, _, _ = ob.tx_generate(seed=5, n_frames=4, subch=ob.subch_layout(1, 64), delay=700, snr_db=15.0, cfo_hz=-900.0, tii=tii)
+        s = ob.Stream()
+        s.push(iq)
+        o = s.process(2)
+        assert o["fib_ok"].all()
+        ids = np.zeros(48, dtype=np.uint8)
+        n = L.dabsdr_amd_tii_detect(s.null_spectrum().ctypes.data, 4.0, ids.ctypes.data, 24)
+        assert (n, tuple(ids[:2 * n])) == ((1, tii) if tii else (0, ()))
