@@ -4,7 +4,6 @@
 // the reference keeps in its global sample FIFO (reference:
 // src/input/inputdevice.cpp:30-131) and the launch sequence of one decode step.
 #include "dabx_kernels.hip"
-#include "dabx_vit64.hip"
 #include "dabx_spec.hpp"
 #include "rawfile.hpp"
 #include "../../include/dabx.h"
@@ -20,7 +19,6 @@
 
 namespace {
 
-constexpr int kLdsMaxSteps = 1984;   // 4 waves x 62 half-blocks x 64 decision words x 4 B = 62 KiB of LDS per workgroup
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
@@ -73,13 +71,6 @@ struct dabx_ctx {
     uint32_t *d_info = nullptr;
     uint32_t *d_prbs = nullptr, *d_scratch = nullptr;
     DevWork *d_work = nullptr;
-    DevGroup *d_groups = nullptr;           // lane-per-codeword groups of 64 same-profile codewords
-    DevWork *d_gcw = nullptr;               // their codewords, 64 per group
-    uint32_t *d_blk_group = nullptr, *d_blk_index = nullptr;
-    int *d_xbuf = nullptr; uint2 *d_decbuf = nullptr;
-    size_t xbuf_words = 0;
-    int n_groups = 0, n_xblocks = 0;
-    bool use_vit64 = false;                 // experimental lane-per-codeword path: DABX_VIT64=1
     float2 *d_W = nullptr, *d_nhi = nullptr, *d_nlo = nullptr;
     int16_t *d_bop = nullptr, *d_nob = nullptr, *d_car = nullptr;
     int8_t *d_pq = nullptr, *d_pdq = nullptr;
@@ -93,7 +84,7 @@ struct dabx_ctx {
     std::vector<int> pool_off;
     std::vector<DevSub> h_sub;
     bool work_dirty = true;
-    int work_frames = 0, n_short = 0, n_long = 0, lds_words = 0;
+    int work_frames = 0, n_work = 0;
     size_t scratch_words = 0;
     std::mutex mu;
 
@@ -158,86 +149,36 @@ int upload_tables(dabx_ctx *c)
     return dev_upload(c->d_prbs, dabx::prbs_words(dabx::kCifBits));
 }
 
-// (re)build the Viterbi work of a step of n_frames frames.  Codewords are bucketed by
-// protection profile; every full bucket of 64 goes to the lane-per-codeword kernels
-// (dabx_vit64.hip), the rest to the wave-per-codeword kernel (k_viterbi).
+// (re)build the Viterbi work of a step of n_frames frames: one item per codeword (4 FIC codewords per
+// frame, one per sub-channel and CIF), longest first, each with its own block of decision words.
 int build_work(dabx_ctx *c, int n_frames)
 {
-    std::vector<DevWork> shorts, longs, gcw;
-    std::vector<DevGroup> groups;
-    std::vector<uint32_t> blk_group, blk_index;
-    std::map<int, std::vector<DevWork>> buckets;          // key = offset of the profile's map in info_pool
-    std::map<int, std::pair<uint32_t, uint32_t>> dims;    // key -> (nsteps, n_in)
+    std::vector<DevWork> all;
     for (int s = 0; s < c->cfg.n_streams; ++s)
         for (int f = 0; f < n_frames; ++f) {
-            for (int cw = 0; cw < 4; ++cw) buckets[0].push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cw), -1, 0u, 774u});
-            dims[0] = {774u, 768u};
+            for (int cw = 0; cw < 4; ++cw) all.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cw), -1, 0u, 774u});
             const auto &sh = c->streams[s];
             for (int cif = 0; cif < 4; ++cif)
-                for (size_t k = 0; k < sh.prof.size(); ++k) {
-                    const uint32_t ns = static_cast<uint32_t>(sh.prof[k].steps());
-                    const int key = c->h_sub[static_cast<size_t>(s) * 64 + k].info_off;
-                    buckets[key].push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cif), static_cast<int8_t>(k), 0u, ns});
-                    dims[key] = {ns, static_cast<uint32_t>(sh.prof[k].n_in)};
-                }
+                for (size_t k = 0; k < sh.prof.size(); ++k)
+                    all.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cif), static_cast<int8_t>(k), 0u,
+                                   static_cast<uint32_t>(sh.prof[k].steps())});
         }
-    size_t scratch = 0;
-    uint64_t xoff = 0;
-    for (auto &kv : buckets) {
-        auto &v = kv.second;
-        size_t full = c->use_vit64 ? v.size() / 64 : 0;
-        for (size_t gidx = 0; gidx < full; ++gidx) {
-            DevGroup g = {};
-            g.nsteps = dims[kv.first].first; g.n_in = dims[kv.first].second; g.info_off = static_cast<uint32_t>(kv.first);
-            g.first_cw = static_cast<uint32_t>(gcw.size());
-            g.x_off = xoff; g.d_off = xoff;
-            xoff += static_cast<uint64_t>(g.nsteps) * 64;
-            gcw.insert(gcw.end(), v.begin() + gidx * 64, v.begin() + (gidx + 1) * 64);
-            for (uint32_t b = 0; b < (g.nsteps + 63) / 64; ++b) { blk_group.push_back(static_cast<uint32_t>(groups.size())); blk_index.push_back(b); }
-            groups.push_back(g);
-        }
-        for (size_t i = full * 64; i < v.size(); ++i) {
-            DevWork w = v[i];
-            if (w.nsteps <= kLdsMaxSteps) shorts.push_back(w);
-            else {
-                w.scratch = static_cast<uint32_t>(scratch);
-                scratch += ((w.nsteps + 31) >> 5) * 64;
-                longs.push_back(w);
-            }
-        }
+    std::stable_sort(all.begin(), all.end(), [](const DevWork &a, const DevWork &b) { return a.nsteps > b.nsteps; });
+    size_t blocks = 0;                                  // in units of 64 words = the decisions of 32 steps
+    for (auto &w : all) {
+        w.scratch = static_cast<uint32_t>(blocks);
+        blocks += (w.nsteps + 31) >> 5;
     }
-    // longest codewords first: groups (one wave each, all resident) and leftovers alike
-    std::stable_sort(groups.begin(), groups.end(), [](const DevGroup &a, const DevGroup &b) { return a.nsteps > b.nsteps; });
-    blk_group.clear(); blk_index.clear();
-    for (size_t gi = 0; gi < groups.size(); ++gi)
-        for (uint32_t b = 0; b < (groups[gi].nsteps + 63) / 64; ++b) { blk_group.push_back(static_cast<uint32_t>(gi)); blk_index.push_back(b); }
-    auto by_len = [](const DevWork &a, const DevWork &b) { return a.nsteps > b.nsteps; };
-    std::stable_sort(shorts.begin(), shorts.end(), by_len);
-    std::stable_sort(longs.begin(), longs.end(), by_len);
-    c->n_short = static_cast<int>(shorts.size());
-    c->n_long = static_cast<int>(longs.size());
-    c->lds_words = shorts.empty() ? 64 : static_cast<int>(((shorts.front().nsteps + 31) >> 5) * 64);
-    std::vector<DevWork> all(shorts);
-    all.insert(all.end(), longs.begin(), longs.end());
+    if (blocks >> 32) return DABX_E_NOMEM;
+    c->n_work = static_cast<int>(all.size());
     int rc;
-    if ((rc = dev_upload(c->d_work, all)) || (rc = dev_upload(c->d_groups, groups)) || (rc = dev_upload(c->d_gcw, gcw)) ||
-        (rc = dev_upload(c->d_blk_group, blk_group)) || (rc = dev_upload(c->d_blk_index, blk_index)))
-        return rc;
-    c->n_groups = static_cast<int>(groups.size());
-    c->n_xblocks = static_cast<int>(blk_group.size());
-    if (scratch > c->scratch_words) {
+    if ((rc = dev_upload(c->d_work, all))) return rc;
+    if (blocks * 64 > c->scratch_words) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         c->d_scratch = nullptr;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_scratch), scratch * sizeof(uint32_t)));
-        c->scratch_words = scratch;
-    }
-    if (xoff > c->xbuf_words) {
-        if (c->d_xbuf) (void)hipFree(c->d_xbuf);
-        if (c->d_decbuf) (void)hipFree(c->d_decbuf);
-        c->d_xbuf = nullptr; c->d_decbuf = nullptr;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_xbuf), xoff * sizeof(int)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_decbuf), xoff * sizeof(uint2)));
-        c->xbuf_words = xoff;
+        c->scratch_words = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_scratch), blocks * 64 * sizeof(uint32_t)) != hipSuccess) return DABX_E_NOMEM;
+        c->scratch_words = blocks * 64;
     }
     c->work_frames = n_frames;
     c->work_dirty = false;
@@ -288,7 +229,6 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
     c->ti_slots = 16;
     while (c->ti_slots < 15 + 4 * cfg->max_frames) c->ti_slots *= 2;
     c->streams.resize(cfg->n_streams);
-    if (const char *e = std::getenv("DABX_VIT64")) c->use_vit64 = std::atoi(e) != 0;    // 1: also use the lane-per-codeword kernels
     const size_t S = cfg->n_streams, F = cfg->max_frames;
 #define ALLOC(ptr, bytes)                                                         \
     do {                                                                          \
@@ -302,7 +242,7 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
     ALLOC(c->d_state, S * sizeof(DevState));
     ALLOC(c->d_sync, S * F * sizeof(DevSync));
     ALLOC(c->d_fic, S * F * DABX_FIC_SOFT_BITS + 64);
-    ALLOC(c->d_ti, S * static_cast<size_t>(c->ti_slots) * DABX_CIF_SOFT_BITS + 64);   // + slack: k_xgather reads up to 3 bytes past a codeword
+    ALLOC(c->d_ti, S * static_cast<size_t>(c->ti_slots) * DABX_CIF_SOFT_BITS + 64);   // + slack for the 4-byte soft-bit fetches
 
     ALLOC(c->d_fib, S * F * 12 * 32);
     ALLOC(c->d_fib_ok, S * F * 12);
@@ -317,8 +257,6 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
     if (rc) { dabx_destroy(c); return rc; }
     c->pool_lookup(dabx::fic_profile());                 // offset 0
     if ((rc = dev_upload(c->d_info, c->info_pool))) { dabx_destroy(c); return rc; }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_viterbi<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               4 * ((kLdsMaxSteps + 31) / 32) * 64 * 4));
     *out = c;
     return DABX_OK;
 }
@@ -328,7 +266,7 @@ void dabx_destroy(dabx_ctx *c)
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
-                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_groups, c->d_gcw, c->d_blk_group, c->d_blk_index, c->d_xbuf, c->d_decbuf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -441,16 +379,7 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     if (u8) hipLaunchKernelGGL(k_demod<0>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
     else hipLaunchKernelGGL(k_demod<1>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
-    if (c->n_groups) {
-        hipLaunchKernelGGL(k_xgather, dim3(c->n_xblocks), dim3(256), 0, q, d, c->d_groups, c->d_gcw, c->d_blk_group, c->d_blk_index, c->d_xbuf);
-        hipLaunchKernelGGL(k_vit64_fwd, dim3(c->n_groups), dim3(64), 0, q, c->d_groups, c->d_xbuf, c->d_decbuf);
-        hipLaunchKernelGGL(k_vit64_tb, dim3(c->n_groups), dim3(64), 0, q, d, c->d_groups, c->d_gcw, c->d_decbuf);
-    }
-    if (c->n_short)
-        hipLaunchKernelGGL(k_viterbi<true>, dim3((c->n_short + 3) / 4), dim3(256), static_cast<size_t>(4) * c->lds_words * 4, q, d,
-                           c->d_work, c->n_short, c->lds_words);
-    if (c->n_long)
-        hipLaunchKernelGGL(k_viterbi<false>, dim3((c->n_long + 3) / 4), dim3(256), 0, q, d, c->d_work + c->n_short, c->n_long, 0);
+    if (c->n_work) hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[3], q));
     hipLaunchKernelGGL(k_finish, dim3(S), dim3(256), 0, q, d, n_frames);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[4], q));

@@ -149,10 +149,8 @@ def test_periodic_ring_round_trip_at_scale(gpu_ctx_factory):
             assert all(m.tobytes() in tx[s][1] for m in gm.reshape(F * 4, -1))
 
 
-def test_lane_per_codeword_path_matches_oracle(gpu_ctx_factory, monkeypatch):
-    # DABX_VIT64=1 routes every full bucket of 64 same-profile codewords through k_xgather /
-    # k_vit64_fwd / k_vit64_tb (experimental, off by default); leftovers stay on k_viterbi.
-    monkeypatch.setenv("DABX_VIT64", "1")
+def test_mixed_profiles_in_one_launch_match_oracle(gpu_ctx_factory):
+    # one Viterbi launch holding codewords of four lengths (FIC, 18 x EEP 3-A, a UEP table entry, EEP A and B)
     subs = [ob.subch_layout(18, 64), [[0, 2, 22, 0], [100, 0, 3, 64], [200, 1, 4, 32]]]
     streams, truth = [], []
     for s in range(2):

@@ -116,5 +116,6 @@ def test_tii_in_null_symbol_is_detected():
         o = s.process(2)
         assert o["fib_ok"].all()
         ids = np.zeros(48, dtype=np.uint8)
-        n = L.dabsdr_amd_tii_detect(s.null_spectrum().ctypes.data, 4.0, ids.ctypes.data, 24)
+        power = s.null_spectrum()                     # keep the array alive across the call
+        n = L.dabsdr_amd_tii_detect(power.ctypes.data, 4.0, ids.ctypes.data, 24)
         assert (n, tuple(ids[:2 * n])) == ((1, tii) if tii else (0, ()))
