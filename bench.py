@@ -205,7 +205,10 @@ def main():
             "roofline": {"kernel": "k_viterbi", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": S * F * BYTES_VITERBI,
-                         "note": "VALU/DPP-bound kernel: HBM fraction is small by construction (SURVEY.md §0.8)",
+                         "note": "VALU-issue-bound kernel (DESIGN.md §7): HBM fraction is small by construction (SURVEY.md §0.8). "
+                                 "traffic = algorithmic bytes + the decision scratch (64 decision bits per trellis step, "
+                                 "written once and read once by the traceback: 2 x 8 B x steps)",
+                         "decision_scratch_bytes_per_launch": 2 * 8 * S * F * (4 * 774 + 4 * args.nsub * 1542),
                          "acs_per_s": round(acs_rate, 0),
                          "chain_algorithmic_GBps": round(value / world / FRAME_S * BYTES_CHAIN / 1e9, 2)},
             "setup_s": {"synthesis": round(t_gen, 1)},
