@@ -85,6 +85,9 @@ struct dabx_ctx {
     std::vector<DevSub> h_sub;
     bool work_dirty = true;
     int work_frames = 0, n_work = 0;
+    hipStream_t copy_stream = nullptr;      // DABX_SRC_PINNED pushes: overlap with the kernels of a step in flight
+    hipEvent_t copy_done = nullptr;
+    bool copies_queued = false;
     size_t scratch_words = 0;
     std::mutex mu;
 
@@ -236,6 +239,8 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
         HIPCHK(hipMemset((ptr), 0, (bytes)));                                     \
     } while (0)
     HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
     ALLOC(c->d_ring, S * static_cast<size_t>(cfg->ring_samples) * c->bps);
     if (cfg->fmt == DABX_FMT_U8) HIPCHK(hipMemset(c->d_ring, 128, S * static_cast<size_t>(cfg->ring_samples) * c->bps));
@@ -265,6 +270,8 @@ void dabx_destroy(dabx_ctx *c)
 {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
                     c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic};
@@ -304,26 +311,77 @@ int dabx_set_subchannels(dabx_ctx *c, int s, int n, const dabx_subch_t *sub)
     return out_off;
 }
 
-int dabx_push(dabx_ctx *c, int s, const void *src, int64_t n, int on_device)
+int dabx_push(dabx_ctx *c, int s, const void *src, int64_t n, int kind)
 {
-    if (!valid_stream(c, s) || n < 0 || (n && !src)) return DABX_E_ARG;
+    if (!valid_stream(c, s) || n < 0 || (n && !src) || kind < DABX_SRC_HOST || kind > DABX_SRC_PINNED) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     auto &sh = c->streams[s];
     const int64_t len = c->cfg.ring_samples;
-    // samples older than (pos - one frame) are no longer needed by any kernel
+    // samples older than (pos - one frame) are no longer needed by any kernel; while a step is in flight
+    // sh.st.pos is still the position before it, so the region its kernels read is protected as well
     if (sh.wr + n - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
     uint8_t *ring = c->d_ring + static_cast<size_t>(s) * len * c->bps;
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind mk = kind == DABX_SRC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    hipStream_t q = kind == DABX_SRC_PINNED ? c->copy_stream : c->stream;
     int64_t done = 0;
     while (done < n) {
         const int64_t w = (sh.wr + done) % len, chunk = std::min(n - done, len - w);
         HIPCHK(hipMemcpyAsync(ring + w * c->bps, static_cast<const uint8_t *>(src) + done * c->bps,
-                              static_cast<size_t>(chunk) * c->bps, kind, c->stream));
+                              static_cast<size_t>(chunk) * c->bps, mk, q));
         done += chunk;
     }
-    if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
+    if (kind == DABX_SRC_HOST) HIPCHK(hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
+    if (kind == DABX_SRC_PINNED) c->copies_queued = true;                 // the next step waits for the copy stream
     sh.wr += n;
     return DABX_OK;
+}
+
+int dabx_push_all(dabx_ctx *c, const void *src, size_t stride, int64_t n, int kind)
+{
+    if (!c || n < 0 || (n && !src) || kind < DABX_SRC_HOST || kind > DABX_SRC_PINNED) return DABX_E_ARG;
+    const int S = c->cfg.n_streams;
+    const int64_t len = c->cfg.ring_samples;
+    bool lockstep = true;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (int s = 0; s < S; ++s) {
+            const auto &sh = c->streams[s];
+            lockstep = lockstep && sh.wr == c->streams[0].wr;
+            if (sh.wr + n - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
+        }
+        if (lockstep && n) {
+            const hipMemcpyKind mk = kind == DABX_SRC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            hipStream_t q = kind == DABX_SRC_PINNED ? c->copy_stream : c->stream;
+            int64_t done = 0;
+            while (done < n) {                       // at most two pieces: the ring wraps at the same place in every stream
+                const int64_t w = (c->streams[0].wr + done) % len, chunk = std::min(n - done, len - w);
+                HIPCHK(hipMemcpy2DAsync(c->d_ring + w * c->bps, static_cast<size_t>(len) * c->bps,
+                                        static_cast<const uint8_t *>(src) + done * c->bps, stride,
+                                        static_cast<size_t>(chunk) * c->bps, S, mk, q));
+                done += chunk;
+            }
+            if (kind == DABX_SRC_HOST) HIPCHK(hipStreamSynchronize(c->stream));
+            if (kind == DABX_SRC_PINNED) c->copies_queued = true;
+            for (auto &sh : c->streams) sh.wr += n;
+            return DABX_OK;
+        }
+    }
+    for (int s = 0; s < S; ++s) {
+        const int rc = dabx_push(c, s, static_cast<const uint8_t *>(src) + s * stride, n, kind);
+        if (rc) return rc;
+    }
+    return DABX_OK;
+}
+
+void *dabx_alloc_pinned(size_t bytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void dabx_free_pinned(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 void *dabx_ring_ptr(dabx_ctx *c, int s)
@@ -369,6 +427,11 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     const DevCtx d = c->dev();
     const int S = c->cfg.n_streams;
     hipStream_t q = c->stream;
+    if (c->copies_queued) {                 // samples pushed from pinned memory must have landed
+        HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
+        HIPCHK(hipStreamWaitEvent(q, c->copy_done, 0));
+        c->copies_queued = false;
+    }
     const bool u8 = c->cfg.fmt == DABX_FMT_U8;
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], q));
     if (u8) hipLaunchKernelGGL(k_null_search<0>, dim3(S), dim3(256), 0, q, d);

@@ -19,7 +19,7 @@ SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("pe
 
 # every symbol include/dabx.h declares; tests check that the library exports them all
 DABX_SYMBOLS = [
-    "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_ring_ptr",
+    "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_push_all", "dabx_alloc_pinned", "dabx_free_pinned", "dabx_ring_ptr",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
     "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum",
@@ -144,6 +144,28 @@ class Context:
     def push(self, stream, iq):
         iq = np.ascontiguousarray(iq)
         _chk(self.L.dabx_push(self.h, stream, iq.ctypes.data, iq.size // 2, 0))
+
+    def push_pinned(self, stream, host_ptr, n_samples):
+        """host_ptr: address inside a buffer from alloc_pinned(); asynchronous (see include/dabx.h)"""
+        _chk(self.L.dabx_push(self.h, stream, C.c_void_p(host_ptr), n_samples, 2))
+
+    def push_all(self, src_ptr, stride_bytes, n_samples, kind=2):
+        """n_samples for every stream, stream s from src_ptr + s * stride_bytes (kind: 0 host, 1 device, 2 pinned)"""
+        self.L.dabx_push_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int]
+        _chk(self.L.dabx_push_all(self.h, C.c_void_p(src_ptr), stride_bytes, n_samples, kind))
+
+    def alloc_pinned(self, n_bytes):
+        """page-locked host buffer as a numpy uint8 array (free with free_pinned)"""
+        self.L.dabx_alloc_pinned.restype = C.c_void_p
+        self.L.dabx_alloc_pinned.argtypes = [C.c_size_t]
+        p = self.L.dabx_alloc_pinned(n_bytes)
+        if not p:
+            raise MemoryError("dabx_alloc_pinned")
+        return np.ctypeslib.as_array((C.c_uint8 * n_bytes).from_address(p))
+
+    def free_pinned(self, arr):
+        self.L.dabx_free_pinned.argtypes = [C.c_void_p]
+        self.L.dabx_free_pinned(C.c_void_p(arr.ctypes.data))
 
     def push_device(self, stream, dev_ptr, n_samples):
         _chk(self.L.dabx_push(self.h, stream, C.c_void_p(dev_ptr), n_samples, 1))

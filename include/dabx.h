@@ -99,10 +99,28 @@ DABX_API const char *dabx_strerror(int code);
 DABX_API int dabx_set_subchannels(dabx_ctx *ctx, int stream, int n, const dabx_subch_t *sub);
 
 /* Append n complex samples (interleaved I,Q in the context's format) to a
- * stream's ring.  src may be host or device memory (src_on_device != 0).
- * Replaces the producer side of the reference's global FIFO
- * (reference: src/input/inputdevice.cpp:30, src/input/rawfileinput.cpp:602-747). */
-DABX_API int dabx_push(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_on_device);
+ * stream's ring.  Replaces the producer side of the reference's global FIFO
+ * (reference: src/input/inputdevice.cpp:30, src/input/rawfileinput.cpp:602-747).
+ *   src_kind DABX_SRC_HOST    pageable host memory; returns when the buffer may be reused
+ *            DABX_SRC_DEVICE  device memory of the context's GPU
+ *            DABX_SRC_PINNED  host memory from dabx_alloc_pinned(): the copy is queued on the context's
+ *                             copy stream and overlaps with a running dabx_process_async(); the buffer
+ *                             must stay untouched until the next dabx_process / dabx_process_async
+ *                             call has returned and its dabx_wait() has completed */
+#define DABX_SRC_HOST   0
+#define DABX_SRC_DEVICE 1
+#define DABX_SRC_PINNED 2
+DABX_API int dabx_push(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_kind);
+
+/* The same for every stream in one call: stream s reads n samples at src + s * src_stride_bytes.  When all
+ * streams stand at the same write position (a batch fed in lock step) this is one strided copy instead of
+ * n_streams copies. */
+DABX_API int dabx_push_all(dabx_ctx *ctx, const void *src, size_t src_stride_bytes, int64_t n, int src_kind);
+
+/* Page-locked host buffers for DABX_SRC_PINNED (a file reader fills them directly, as RawFileWorker
+ * fills its read buffer: reference src/input/rawfileinput.cpp:640-713). */
+DABX_API void *dabx_alloc_pinned(size_t bytes);
+DABX_API void  dabx_free_pinned(void *p);
 
 /* Device address of a stream's ring and a way to declare samples resident
  * without copying (zero-copy producers, and the benchmark's periodic signal). */

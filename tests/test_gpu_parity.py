@@ -179,6 +179,43 @@ def test_signal_spectrum_matches_oracle(gpu_ctx_factory):
     assert g[band].mean() > 50 * g[800:1248].mean()                          # 1536 carriers stand out of the guard band
 
 
+def test_pinned_overlapped_ingest_matches_oracle(gpu_ctx_factory):
+    """Streaming through the host boundary the way a file reader would: page-locked staging, one strided
+    dabx_push_all per step queued while the previous step decodes (dabx_process_async) — same output as the
+    oracle fed with the same samples."""
+    S, F, steps = 3, 2, 4
+    sub = ob.subch_layout(3, 64)
+    n_total = (F * steps + 2) * ob.TF
+    ctx = gpu_ctx_factory(n_streams=S, fmt=0, ring_frames=2 * F + 4, max_frames=F)
+    stage = ctx.alloc_pinned(S * n_total * 2)
+    oracles = []
+    for s in range(S):
+        iq, _, _ = ob.tx_generate(seed=300 + s, n_frames=F * steps + 2, subch=sub, delay=900 * s, snr_db=18.0, cfo_hz=700.0 * s)
+        stage[s * n_total * 2:(s + 1) * n_total * 2] = iq[:n_total * 2]
+        ctx.set_subchannels(s, sub)
+        o = ob.Stream(fmt=0, subch=sub, ring_len=n_total + ob.TF, ti_slots=64)
+        o.push(iq[:n_total * 2])
+        oracles.append(o)
+    pos = (F + 1) * ob.TF + 4096
+    ctx.push_all(stage.ctypes.data, n_total * 2, pos, kind=2)
+    for k in range(steps):
+        ctx.process_async(F)
+        n = min(F * ob.TF, n_total - pos)
+        if n > 0:                                   # travels while the step above decodes
+            ctx.push_all(stage.ctypes.data + pos * 2, n_total * 2, n, kind=2)
+            pos += n
+        ctx.wait()
+        for s, orc in enumerate(oracles):
+            o = orc.process(F)
+            assert o["rc"] == F
+            gf, gok = ctx.fib(s)
+            assert np.array_equal(gok, o["fib_ok"]) and np.array_equal(gf, o["fib"])
+            gm, gv = ctx.msc(s)
+            assert np.array_equal(gv, o["msc_valid"]) and np.array_equal(gm[gv == 1], o["msc"][o["msc_valid"] == 1])
+    assert ctx.fib_counts()[1] == 0
+    ctx.free_pinned(stage)
+
+
 def test_null_spectrum_matches_oracle_and_carries_tii(gpu_ctx_factory):
     import ctypes as C
     sub = ob.subch_layout(2, 64)
