@@ -73,6 +73,7 @@ struct dabsdr_s {
     dabplus::Decoder aac;                 // DAB+ super frame -> access units
     dabplus::Stats last_stats;
     uint32_t audio_bytes_acc = 0;
+    std::vector<figdb::UserApp> app_snapshot;
     bool spectrum_on = false, tii_on = false;
     int tii_mode = DABSDR_TII_MODE_DEFAULT;
     std::vector<float> spectrum, null_power;
@@ -130,11 +131,21 @@ int get_component_item(dabsdrHandle_t h, uint8_t idx, dabsdrServiceCompListItem_
     out->SCIdS = static_cast<uint8_t>(c.scids);
     out->SubChAddr = -1;
     out->ps = c.primary ? 1 : 0;
-    out->lang = 0;
     out->CAflag = c.ca;
     out->TMId = static_cast<uint8_t>(c.tmid);
+    out->numUserApps = static_cast<uint8_t>(c.apps.size());
     fill_label(out->label, c.label, c.label_flag);
-    auto it = h->db.subch.find(c.subch);
+    int subch = c.subch;
+    if (c.tmid == 3) {                                  // packet mode: FIG 0/3 links the SCId to a sub-channel
+        auto pk = h->db.packet.find(c.scid);
+        if (pk != h->db.packet.end()) subch = pk->second.subch;
+        auto lg = h->db.language_scid.find(c.scid);
+        if (lg != h->db.language_scid.end()) out->lang = static_cast<uint8_t>(lg->second);
+    } else {
+        auto lg = h->db.language.find(c.subch);
+        if (lg != h->db.language.end()) out->lang = static_cast<uint8_t>(lg->second);
+    }
+    auto it = h->db.subch.find(subch);
     if (c.tmid != 3 && it != h->db.subch.end()) {
         const figdb::SubChannel &sc = it->second;
         out->SubChId = static_cast<uint8_t>(sc.id);
@@ -147,6 +158,21 @@ int get_component_item(dabsdrHandle_t h, uint8_t idx, dabsdrServiceCompListItem_
     } else if (c.tmid == 3) {
         out->packetData.SCId = static_cast<uint16_t>(c.scid);
         out->packetData.packetAddress = -1;
+        auto pk = h->db.packet.find(c.scid);
+        if (pk != h->db.packet.end()) {
+            out->packetData.DSCTy = static_cast<uint8_t>(pk->second.dscty);
+            out->packetData.DGflag = pk->second.dg_flag ? 1 : 0;
+            out->packetData.packetAddress = static_cast<int16_t>(pk->second.packet_address);
+            if (it != h->db.subch.end()) {
+                const figdb::SubChannel &sc = it->second;
+                out->SubChId = static_cast<uint8_t>(sc.id);
+                out->SubChAddr = static_cast<int16_t>(sc.start);
+                out->SubChSize = static_cast<uint16_t>(sc.size);
+                out->protectionLevel = static_cast<uint8_t>(protection_enum(sc));
+                auto fe = h->db.fec_scheme.find(sc.id);
+                out->fecScheme = fe != h->db.fec_scheme.end() ? static_cast<uint8_t>(fe->second) : 0;
+            }
+        }
     }
     return 0;
 }
@@ -226,14 +252,33 @@ void handle_request(dabsdr_s *h, const Request &r)
         dabsdrNtfUserAppList_t l;
         std::memset(&l, 0, sizeof l);
         l.SId = r.a; l.SCIdS = static_cast<uint8_t>(r.b);
-        l.getUserAppListItem = [](dabsdrHandle_t, uint8_t, dabsdrUserAppListItem_t *) { return -1; };
-        notify(h, DABSDR_NID_USER_APP_LIST, DABSDR_NSTAT_SUCCESS, &l, sizeof l);
+        h->app_snapshot.clear();
+        const figdb::Service *s = h->db.find_service(r.a);
+        if (s)
+            for (const auto &c : s->comp)
+                if (c.scids == static_cast<int>(r.b)) h->app_snapshot = c.apps;
+        l.numUserApps = static_cast<uint8_t>(h->app_snapshot.size());
+        l.getUserAppListItem = [](dabsdrHandle_t hh, uint8_t idx, dabsdrUserAppListItem_t *out) {
+            if (!hh || !out || idx >= hh->app_snapshot.size()) return -1;
+            const figdb::UserApp &a = hh->app_snapshot[idx];
+            std::memset(out, 0, sizeof *out);
+            out->type = static_cast<uint16_t>(a.type);
+            out->dataLen = static_cast<uint8_t>(std::min<size_t>(a.data.size(), sizeof out->data));
+            std::memcpy(out->data, a.data.data(), out->dataLen);
+            return 0;
+        };
+        notify(h, DABSDR_NID_USER_APP_LIST, s ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_SERVICE_NOT_FOUND, &l, sizeof l);
         break;
     }
     case Req::GetAnnouncementSupport: {
         dabsdrNtfAnnouncementSupport_t a;
         std::memset(&a, 0, sizeof a);
         a.SId = r.a;
+        if (const figdb::Service *s = h->db.find_service(r.a)) {
+            a.ASu = s->asu;
+            a.numClusterIds = static_cast<uint8_t>(std::min<size_t>(s->clusters.size(), sizeof a.clusterIds));
+            std::memcpy(a.clusterIds, s->clusters.data(), a.numClusterIds);
+        }
         notify(h, DABSDR_NID_ANNOUNCEMENT_SUPPORT, DABSDR_NSTAT_SUCCESS, &a, sizeof a);
         break;
     }
@@ -347,6 +392,23 @@ void after_step(dabsdr_s *h)
     const double sig = static_cast<double>(rec.e_sig);
     if (noise > 0 && sig > noise) snr10 = static_cast<int16_t>(std::min(600L, std::lround(100.0 * std::log10((sig - noise) / noise))));
     else if (sig > 0 && noise <= 0) snr10 = 600;
+    for (uint32_t sid : h->db.pty_changed)                // FIG 0/17 -> DABSDR_NID_PTY (dabsdr.h:353-357)
+        if (const figdb::Service *sv = h->db.find_service(sid)) {
+            dabsdrNtfPTy_t p = {sid, static_cast<uint8_t>(sv->pty), static_cast<uint8_t>(sv->pty)};
+            notify(h, DABSDR_NID_PTY, DABSDR_NSTAT_SUCCESS, &p, sizeof p);
+        }
+    h->db.pty_changed.clear();
+    if (h->db.switching_changed) {                        // FIG 0/19 -> DABSDR_NID_ANNOUNCEMENT_SWITCHING (dabsdr.h:341-351)
+        h->db.switching_changed = false;
+        dabsdrNtfAnnouncementSwitching_t a;
+        std::memset(&a, 0, sizeof a);
+        int k = 0;
+        for (const auto &kv : h->db.switching) {
+            if (k >= 8) break;
+            a.asw[k++] = {static_cast<uint8_t>(kv.second.cluster), static_cast<uint8_t>(kv.second.subch), kv.second.flags};
+        }
+        notify(h, DABSDR_NID_ANNOUNCEMENT_SWITCHING, DABSDR_NSTAT_SUCCESS, &a, sizeof a);
+    }
     if (lvl != h->sync_level) {
         h->sync_level = lvl;
         dabsdrNtfSyncStatus_t s = {lvl, snr10};
@@ -601,6 +663,37 @@ DABSDR_API int dabsdr_amd_fig_dump(const uint8_t *fibs, int n_fibs, char *out, i
             s += line;
         }
         s += "\n";
+        if (kv.second.pty >= 0 || kv.second.asu || !kv.second.clusters.empty()) {
+            std::snprintf(line, sizeof line, "  pty=%d dyn=%d asu=%04X clusters=", kv.second.pty, kv.second.pty_dynamic ? 1 : 0, kv.second.asu);
+            s += line;
+            for (uint8_t cl : kv.second.clusters) { std::snprintf(line, sizeof line, "%d,", cl); s += line; }
+            s += "\n";
+        }
+        for (const auto &c : kv.second.comp) {
+            if (!c.scids_known && c.apps.empty() && c.tmid != 3) continue;
+            std::snprintf(line, sizeof line, "  comp scids=%d scid=%d apps=", c.scids, c.scid);
+            s += line;
+            for (const auto &a : c.apps) {
+                std::snprintf(line, sizeof line, "%03X:", a.type);
+                s += line;
+                for (uint8_t b : a.data) { std::snprintf(line, sizeof line, "%02X", b); s += line; }
+                s += ",";
+            }
+            s += "\n";
+        }
+    }
+    for (const auto &kv : db.language) { std::snprintf(line, sizeof line, "language subch=%d code=%d\n", kv.first, kv.second); s += line; }
+    for (const auto &kv : db.language_scid) { std::snprintf(line, sizeof line, "language scid=%d code=%d\n", kv.first, kv.second); s += line; }
+    for (const auto &kv : db.packet) {
+        std::snprintf(line, sizeof line, "packet scid=%d subch=%d dscty=%d addr=%d dg=%d\n", kv.second.scid, kv.second.subch, kv.second.dscty,
+                      kv.second.packet_address, kv.second.dg_flag ? 1 : 0);
+        s += line;
+    }
+    for (const auto &kv : db.fec_scheme) { std::snprintf(line, sizeof line, "fec subch=%d scheme=%d\n", kv.first, kv.second); s += line; }
+    for (const auto &kv : db.switching) {
+        std::snprintf(line, sizeof line, "switching cluster=%d flags=%04X subch=%d new=%d\n", kv.second.cluster, kv.second.flags, kv.second.subch,
+                      kv.second.new_flag ? 1 : 0);
+        s += line;
     }
     if (static_cast<int>(s.size()) + 1 > cap) return -1;
     std::memcpy(out, s.c_str(), s.size() + 1);

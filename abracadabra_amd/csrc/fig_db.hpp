@@ -5,8 +5,8 @@
 // dabsdrNtfEnsemble_t, dabsdrServiceListItem_t and dabsdrServiceCompListItem_t
 // (reference: lib/linux_x86_64/dabsdr.h:176-243, :301-318; consumer
 // src/radiocontrol.cpp:1381-1570).  The reference's parser is closed source;
-// this one follows the standard.  Supported: FIG 0/0, 0/1, 0/2, 0/9, 0/10,
-// 0/17, 1/0, 1/1, 1/4.  Unknown FIGs are skipped by their length field.
+// this one follows the standard.  Supported: FIG 0/0, 0/1, 0/2, 0/3, 0/5, 0/8, 0/9, 0/10,
+// 0/13, 0/14, 0/17, 0/18, 0/19, 1/0, 1/1, 1/4, 1/5.  Unknown FIGs are skipped by their length field.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -26,6 +26,11 @@ struct SubChannel {
     int kbps = 0;
 };
 
+struct UserApp {
+    int type = 0;                     // 11-bit user application type (TS 101 756 table 16)
+    std::vector<uint8_t> data;        // user application data field (X-PAD: CA/AppTy byte, DG/DSCTy byte, ...)
+};
+
 struct Component {
     int tmid = 0;
     int ascty_dscty = 0;
@@ -33,8 +38,21 @@ struct Component {
     int scid = -1;                    // packet mode
     bool primary = false, ca = false;
     int scids = -1;                   // from FIG 0/8, else position
+    bool scids_known = false;
     std::string label;
     uint16_t label_flag = 0;
+    std::vector<UserApp> apps;        // FIG 0/13
+};
+
+struct PacketComponent {              // FIG 0/3
+    int scid = -1, subch = -1, dscty = 0, packet_address = -1;
+    bool dg_flag = false, ca_org = false;
+};
+
+struct AnnouncementSwitch {           // FIG 0/19
+    int cluster = 0, subch = 0;
+    uint16_t flags = 0;
+    bool new_flag = false;
 };
 
 struct Service {
@@ -45,6 +63,9 @@ struct Service {
     std::string label;
     uint16_t label_flag = 0;
     int pty = -1;
+    bool pty_dynamic = false;
+    uint16_t asu = 0;                 // FIG 0/18 announcement support flags
+    std::vector<uint8_t> clusters;
 };
 
 struct Ensemble {
@@ -62,6 +83,13 @@ public:
     Ensemble ens;
     std::map<int, SubChannel> subch;
     std::map<uint32_t, Service> services;
+    std::map<int, int> language;                      // FIG 0/5 short form: SubChId -> language code
+    std::map<int, int> language_scid;                 // FIG 0/5 long form: SCId -> language code
+    std::map<int, PacketComponent> packet;            // FIG 0/3 by SCId
+    std::map<int, int> fec_scheme;                    // FIG 0/14: SubChId -> FEC scheme
+    std::map<int, AnnouncementSwitch> switching;      // FIG 0/19 by cluster id
+    std::vector<uint32_t> pty_changed;                // SIds whose PTy changed since the owner last looked
+    bool switching_changed = false;
     int fibs_seen = 0;
 
     void clear() { *this = Database(); }
@@ -189,12 +217,122 @@ private:
                 ens.utc_valid = true;
             }
             break;
-        case 17:
-            while (n >= 4) {
-                const uint32_t sid = (p[0] << 8) | p[1];
+        case 3:                       // service component in packet mode
+            while (n >= 5) {
+                PacketComponent pc;
+                pc.scid = (p[0] << 4) | (p[1] >> 4);
+                pc.ca_org = p[1] & 1;
+                pc.dg_flag = !((p[2] >> 7) & 1);      // the bit says "data groups are NOT used"
+                pc.dscty = p[2] & 0x3F;
+                pc.subch = p[3] >> 2;
+                pc.packet_address = ((p[3] & 3) << 8) | p[4];
+                const int step = pc.ca_org ? 7 : 5;
+                if (n < step) return;
+                packet[pc.scid] = pc;
+                p += step; n -= step;
+            }
+            break;
+        case 5:                       // service component language
+            while (n >= 2) {
+                if (p[0] & 0x80) {                    // long form: SCId
+                    if (n < 3) return;
+                    language_scid[((p[0] & 0x0F) << 8) | p[1]] = p[2];
+                    p += 3; n -= 3;
+                } else {
+                    language[p[0] & 0x3F] = p[1];
+                    p += 2; n -= 2;
+                }
+            }
+            break;
+        case 8:                       // service component global definition: SCIdS <-> SubChId / SCId
+            while (n >= (pd ? 6 : 4)) {
+                uint32_t sid;
+                if (pd) { sid = (uint32_t(p[0]) << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; p += 4; n -= 4; }
+                else { sid = (p[0] << 8) | p[1]; p += 2; n -= 2; }
+                const bool ext = p[0] >> 7;
+                const int scids = p[0] & 0x0F;
+                const bool ls = p[1] >> 7;
+                int subch = -1, scid = -1, used = 2;
+                if (ls) { if (n < 3) return; scid = ((p[1] & 0x0F) << 8) | p[2]; used = 3; }
+                else subch = p[1] & 0x3F;
+                if (ext) ++used;                      // Rfa byte
+                if (n < used) return;
                 auto it = services.find(sid);
-                if (it != services.end()) it->second.pty = p[3] & 0x1F;
-                p += 4; n -= 4;
+                if (it != services.end())
+                    for (auto &c : it->second.comp)
+                        if ((subch >= 0 && c.tmid != 3 && c.subch == subch) || (scid >= 0 && c.tmid == 3 && c.scid == scid)) {
+                            c.scids = scids; c.scids_known = true;
+                        }
+                p += used; n -= used;
+            }
+            break;
+        case 13:                      // user application information
+            while (n >= (pd ? 5 : 3)) {
+                uint32_t sid;
+                if (pd) { sid = (uint32_t(p[0]) << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; p += 4; n -= 4; }
+                else { sid = (p[0] << 8) | p[1]; p += 2; n -= 2; }
+                const int scids = p[0] >> 4, napps = p[0] & 0x0F;
+                ++p; --n;
+                std::vector<UserApp> apps;
+                for (int i = 0; i < napps; ++i) {
+                    if (n < 2) return;
+                    UserApp a;
+                    a.type = (p[0] << 3) | (p[1] >> 5);
+                    const int dl = p[1] & 0x1F;
+                    if (n < 2 + dl) return;
+                    a.data.assign(p + 2, p + 2 + dl);
+                    apps.push_back(a);
+                    p += 2 + dl; n -= 2 + dl;
+                }
+                auto it = services.find(sid);
+                if (it != services.end())
+                    for (auto &c : it->second.comp)
+                        if (c.scids == scids) c.apps = apps;
+            }
+            break;
+        case 14:                      // FEC sub-channel organisation (packet mode)
+            while (n >= 1) { fec_scheme[p[0] >> 2] = p[0] & 3; ++p; --n; }
+            break;
+        case 17:
+            while (n >= 4) {          // editions before V2.1.1 may carry a language (L) and a complementary code (CC)
+                const uint32_t sid = (p[0] << 8) | p[1];
+                const int l = (p[2] >> 5) & 1, cc = (p[2] >> 4) & 1, used = 4 + l + cc;
+                if (n < used) return;
+                auto it = services.find(sid);
+                if (it != services.end()) {
+                    const int pty = p[3 + l] & 0x1F;
+                    const bool dyn = p[2] >> 7;
+                    if (it->second.pty != pty || it->second.pty_dynamic != dyn) pty_changed.push_back(sid);
+                    it->second.pty = pty; it->second.pty_dynamic = dyn;
+                }
+                p += used; n -= used;
+            }
+            break;
+        case 18:                      // announcement support
+            while (n >= 5) {
+                const uint32_t sid = (p[0] << 8) | p[1];
+                const uint16_t asu = uint16_t((p[2] << 8) | p[3]);
+                const int ncl = p[4] & 0x1F;
+                if (n < 5 + ncl) return;
+                auto it = services.find(sid);
+                if (it != services.end()) { it->second.asu = asu; it->second.clusters.assign(p + 5, p + 5 + ncl); }
+                p += 5 + ncl; n -= 5 + ncl;
+            }
+            break;
+        case 19:                      // announcement switching
+            while (n >= 4) {
+                AnnouncementSwitch a;
+                a.cluster = p[0];
+                a.flags = uint16_t((p[1] << 8) | p[2]);
+                a.new_flag = p[3] >> 7;
+                const bool region = (p[3] >> 6) & 1;
+                a.subch = p[3] & 0x3F;
+                const int used = region ? 5 : 4;
+                if (n < used) return;
+                auto it = switching.find(a.cluster);
+                if (it == switching.end() || it->second.flags != a.flags || it->second.subch != a.subch) switching_changed = true;
+                switching[a.cluster] = a;
+                p += used; n -= used;
             }
             break;
         default: break;

@@ -27,6 +27,7 @@ typedef struct {
     int32_t  subch[64][4]; /* {start_cu, option(0=A,1=B,2=UEP), level, kbps} */
     int32_t  payload_given;/* 1: msc_out already holds the payload to transmit    */
     int32_t  tii_main, tii_sub; /* TII in every null symbol (EN 300 401 §14.8); main < 0: none */
+    int32_t  extra_figs;   /* 1: also send FIG 0/5, 0/8, 0/13, 0/17, 0/18, 0/19 for the first service */
 } dab_tx_cfg_t;
 
 /* ---- deterministic PRNG (splitmix64) ---- */
@@ -134,6 +135,19 @@ static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *f
         lab[8] = (char)('0' + s / 10); lab[9] = (char)('0' + s % 10);
         f->b[0] = 0x20 | 21; f->b[1] = 0x01; f->b[2] = (uint8_t)(sid >> 8); f->b[3] = (uint8_t)sid;
         memcpy(f->b + 4, lab, 16); f->b[20] = 0xFF; f->b[21] = 0x00; f->len = 22;
+    }
+    if (c->extra_figs && c->n_subch > 0) {
+        const int sid = 0x1A01;
+        static const uint8_t lang[] = {0x03, 0x05, 0x00, 0x09};                                   /* 0/5: SubCh 0, English          */
+        static const uint8_t glob[] = {0x05, 0x08, 0x1A, 0x01, 0x00, 0x00};                       /* 0/8: SCIdS 0 <-> SubCh 0       */
+        static const uint8_t apps[] = {0x08, 0x0D, 0x1A, 0x01, 0x01, 0x00, 0x42, 0x0C, 0x3C};     /* 0/13: SLS (type 2) over X-PAD  */
+        static const uint8_t pty[]  = {0x05, 0x11, 0x1A, 0x01, 0x00, 0x0A};                       /* 0/17: PTy 10 (pop music)       */
+        static const uint8_t asu[]  = {0x07, 0x12, 0x1A, 0x01, 0x00, 0x02, 0x01, 0x07};           /* 0/18: traffic, cluster 7       */
+        static const uint8_t asw[]  = {0x05, 0x13, 0x07, 0x00, 0x02, 0x80};                       /* 0/19: cluster 7 on SubCh 0     */
+        const uint8_t *src[] = {lang, glob, apps, pty, asu, asw};
+        const int len[] = {sizeof lang, sizeof glob, sizeof apps, sizeof pty, sizeof asu, sizeof asw};
+        (void)sid;
+        for (int k = 0; k < 6; k++) { fig_t *f = &figs[n++]; memcpy(f->b, src[k], (size_t)len[k]); f->len = len[k]; }
     }
     return n;
 }

@@ -14,7 +14,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 NID = dict(SYNC_STATUS=1, TUNE=2, ENSEMBLE_INFO=3, SERVICE_LIST=4, SERVICE_COMPONENT_LIST=5, SERVICE_SELECTION=8,
-           PERIODIC=10, RESET=13, TII=17)
+           USER_APP_LIST=7, PERIODIC=10, RESET=13, ANNOUNCEMENT_SUPPORT=14, ANNOUNCEMENT_SWITCHING=15, PTY=16, TII=17)
 
 
 class Label(C.Structure):
@@ -41,6 +41,45 @@ class Ntf(C.Structure):
     _fields_ = [("nid", C.c_int), ("status", C.c_int), ("len", C.c_uint16), ("pData", C.c_void_p)]
 
 
+class CompItem(C.Structure):                       # dabsdrServiceCompListItem_t (dabsdr.h:193-243)
+    class _U(C.Union):
+        class _A(C.Structure):
+            _fields_ = [("ASCTy", C.c_uint8), ("bitRate", C.c_uint16)]
+
+        class _P(C.Structure):
+            _fields_ = [("DSCTy", C.c_uint8), ("SCId", C.c_uint16), ("DGflag", C.c_uint8), ("packetAddress", C.c_int16)]
+        _fields_ = [("streamAudio", _A), ("packetData", _P)]
+    _fields_ = [("SCIdS", C.c_uint8), ("SubChId", C.c_uint8), ("SubChAddr", C.c_int16), ("SubChSize", C.c_uint16),
+                ("protectionLevel", C.c_uint8), ("uepIdx", C.c_uint8), ("ps", C.c_uint8), ("lang", C.c_uint8), ("CAflag", C.c_uint8),
+                ("label", Label), ("numUserApps", C.c_uint8), ("TMId", C.c_uint8), ("u", _U)]
+
+
+class CompList(C.Structure):
+    _fields_ = [("SId", C.c_uint32), ("numServiceComponents", C.c_uint8),
+                ("getItem", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint8, C.POINTER(CompItem)))]
+
+
+class UserAppItem(C.Structure):
+    _fields_ = [("type", C.c_uint16), ("label", Label), ("dataLen", C.c_uint8), ("data", C.c_uint8 * 23)]
+
+
+class UserAppList(C.Structure):
+    _fields_ = [("SId", C.c_uint32), ("SCIdS", C.c_uint8), ("numUserApps", C.c_uint8),
+                ("getItem", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint8, C.POINTER(UserAppItem)))]
+
+
+class AnnSupport(C.Structure):
+    _fields_ = [("SId", C.c_uint32), ("ASu", C.c_uint16), ("numClusterIds", C.c_uint8), ("clusterIds", C.c_uint8 * 7)]
+
+
+class Asw(C.Structure):
+    _fields_ = [("clusterId", C.c_uint8), ("subChId", C.c_uint8), ("ASwFlags", C.c_uint16)]
+
+
+class PTy(C.Structure):
+    _fields_ = [("SId", C.c_uint32), ("s", C.c_uint8), ("d", C.c_uint8)]
+
+
 class TiiId(C.Structure):
     _fields_ = [("main", C.c_uint8), ("sub", C.c_uint8), ("level", C.c_float)]
 
@@ -61,7 +100,7 @@ def test_tune_lock_ensemble_and_service_list():
     L = aa.load_library()
     cfo = 1500.0
     sub = [[0, 0, 3, 64], [48, 1, 4, 32]]
-    iq, fib, _ = ob.tx_generate(seed=77, eid=0x1234, n_frames=24, subch=sub, delay=5000, snr_db=25.0, cfo_hz=cfo, tii=(21, 5))
+    iq, fib, _ = ob.tx_generate(seed=77, eid=0x1234, n_frames=24, subch=sub, delay=5000, snr_db=25.0, cfo_hz=cfo, tii=(21, 5), extra_figs=True)
     samples = (iq.astype(np.float32) - 128.0)              # what RawFileWorker produces (rawfileinput.cpp:692)
     pos = [0]
     events, lock = [], threading.Lock()
@@ -90,6 +129,32 @@ def test_tune_lock_ensemble_and_service_list():
         elif n.nid == NID["PERIODIC"] and n.pData:
             pr = C.cast(n.pData, C.POINTER(Periodic)).contents
             rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel, dhm=pr.dateHoursMinutes, secms=pr.secMsec)
+        elif n.nid == NID["SERVICE_COMPONENT_LIST"]:
+            cl = C.cast(n.pData, C.POINTER(CompList)).contents
+            comps = []
+            for i in range(cl.numServiceComponents):
+                it = CompItem()
+                cl.getItem(handle, i, C.byref(it))
+                comps.append(dict(scids=it.SCIdS, subch=it.SubChId, addr=it.SubChAddr, size=it.SubChSize, lang=it.lang, napps=it.numUserApps,
+                                  tmid=it.TMId, ascty=it.u.streamAudio.ASCTy, kbps=it.u.streamAudio.bitRate, ps=it.ps))
+            rec.update(sid=cl.SId, comps=comps)
+        elif n.nid == NID["USER_APP_LIST"]:
+            ul = C.cast(n.pData, C.POINTER(UserAppList)).contents
+            apps = []
+            for i in range(ul.numUserApps):
+                it = UserAppItem()
+                ul.getItem(handle, i, C.byref(it))
+                apps.append((it.type, bytes(it.data[:it.dataLen])))
+            rec.update(sid=ul.SId, scids=ul.SCIdS, apps=apps)
+        elif n.nid == NID["ANNOUNCEMENT_SUPPORT"]:
+            a = C.cast(n.pData, C.POINTER(AnnSupport)).contents
+            rec.update(sid=a.SId, asu=a.ASu, clusters=list(a.clusterIds[:a.numClusterIds]))
+        elif n.nid == NID["ANNOUNCEMENT_SWITCHING"]:
+            a = C.cast(n.pData, C.POINTER(Asw * 8)).contents
+            rec.update(asw=[(x.clusterId, x.subChId, x.ASwFlags) for x in a if x.ASwFlags])
+        elif n.nid == NID["PTY"]:
+            y = C.cast(n.pData, C.POINTER(PTy)).contents
+            rec.update(sid=y.SId, s=y.s, d=y.d)
         elif n.nid == NID["TII"]:
             t = C.cast(n.pData, C.POINTER(NtfTii)).contents
             spec = (C.c_float * 384)()                       # the host's buffer size (radiocontrol.h:280)
@@ -155,6 +220,21 @@ def test_tune_lock_ensemble_and_service_list():
     sl = wait_for(lambda e: e["nid"] == NID["SERVICE_LIST"])[-1]
     assert sorted(s[0] for s in sl["services"]) == [0x1A01, 0x1A02]
     assert all(lbl.startswith("SERVICE 0") for _, lbl in sl["services"])
+    # the rest of the start-up sequence of radiocontrol.cpp:1381-1870: components, user applications, announcements
+    L.dabsdrRequest_GetServiceComponents.argtypes = [C.c_void_p, C.c_uint32]
+    L.dabsdrRequest_GetUserAppList.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8]
+    L.dabsdrRequest_GetAnnouncementSupport.argtypes = [C.c_void_p, C.c_uint32]
+    L.dabsdrRequest_GetServiceComponents(handle, 0x1A01)
+    cl = wait_for(lambda e: e["nid"] == NID["SERVICE_COMPONENT_LIST"] and e.get("sid") == 0x1A01)[-1]
+    assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, lang=9, napps=1, tmid=0, ascty=63, kbps=64, ps=1)]
+    L.dabsdrRequest_GetUserAppList(handle, 0x1A01, 0)
+    ul = wait_for(lambda e: e["nid"] == NID["USER_APP_LIST"] and e.get("sid") == 0x1A01)[-1]
+    assert ul["scids"] == 0 and ul["apps"] == [(2, bytes([0x0C, 0x3C]))]                # MOT slide show over X-PAD application type 12
+    L.dabsdrRequest_GetAnnouncementSupport(handle, 0x1A01)
+    an = wait_for(lambda e: e["nid"] == NID["ANNOUNCEMENT_SUPPORT"] and e.get("sid") == 0x1A01)[-1]
+    assert an["asu"] == 0x0002 and an["clusters"] == [7]
+    assert wait_for(lambda e: e["nid"] == NID["ANNOUNCEMENT_SWITCHING"])[-1]["asw"] == [(7, 0, 0x0002)]
+    assert wait_for(lambda e: e["nid"] == NID["PTY"] and e.get("sid") == 0x1A01)[-1]["s"] == 10
     L.dabsdrRequest_Exit(handle)
     L.dabsdrDeinit.argtypes = [C.POINTER(C.c_void_p)]
     L.dabsdrDeinit(C.byref(handle))
