@@ -4,11 +4,13 @@
 // the reference keeps in its global sample FIFO (reference:
 // src/input/inputdevice.cpp:30-131) and the launch sequence of one decode step.
 #include "dabx_kernels.hip"
+#include "dabx_superframe.hip"
 #include "dabx_spec.hpp"
 #include "rawfile.hpp"
 #include "../../include/dabx.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +48,7 @@ struct StreamHost {
     std::vector<dabx_subch_t> sub;
     std::vector<dabx::Profile> prof;
     int msc_bytes = 0;
+    uint64_t dabplus = 0;                   // bit k: sub-channel k carries DAB+ audio (dabx_set_dabplus)
 };
 
 }  // namespace
@@ -85,6 +88,11 @@ struct dabx_ctx {
     std::vector<DevSub> h_sub;
     bool work_dirty = true;
     int work_frames = 0, n_work = 0;
+    // DAB+ super frame stage (dabx_superframe.hip)
+    std::vector<DevSfSub> sf_subs;
+    DevSfSub *d_sf_subs = nullptr; DevSfState *d_sf_state = nullptr; DevSfRec *d_sf_recs = nullptr; uint8_t *d_sf_data = nullptr, *d_gf = nullptr;
+    bool sf_dirty = false;
+    int sf_max_rec = 0;
     hipStream_t copy_stream = nullptr;      // DABX_SRC_PINNED pushes: overlap with the kernels of a step in flight
     hipEvent_t copy_done = nullptr;
     bool copies_queued = false;
@@ -188,6 +196,47 @@ int build_work(dabx_ctx *c, int n_frames)
     return DABX_OK;
 }
 
+// (re)build the list of DAB+ sub-channels; their synchronisation state starts afresh
+int build_superframe_work(dabx_ctx *c)
+{
+    c->sf_subs.clear();
+    c->sf_max_rec = (4 + 4 * c->cfg.max_frames) / 5;
+    uint32_t rec = 0, data = 0;
+    for (int s = 0; s < c->cfg.n_streams; ++s) {
+        const auto &sh = c->streams[s];
+        for (size_t k = 0; k < sh.sub.size() && k < 64; ++k) {
+            if (!((sh.dabplus >> k) & 1)) continue;
+            const int kbps = sh.prof[k].n_in / 24;                    // n_in = 24 ms x kbps
+            if (kbps < 8 || kbps > 192 || kbps % 8) return DABX_E_PROFILE;
+            DevSfSub d = {s, static_cast<int32_t>(k), kbps / 8, 3 * kbps, c->h_sub[static_cast<size_t>(s) * 64 + k].out_off, rec, data, 0u};
+            rec += static_cast<uint32_t>(c->sf_max_rec);
+            data += static_cast<uint32_t>(c->sf_max_rec) * 110u * static_cast<uint32_t>(kbps / 8);
+            c->sf_subs.push_back(d);
+        }
+    }
+    for (void *p : {static_cast<void *>(c->d_sf_subs), static_cast<void *>(c->d_sf_state), static_cast<void *>(c->d_sf_recs), static_cast<void *>(c->d_sf_data)})
+        if (p) (void)hipFree(p);
+    c->d_sf_subs = nullptr; c->d_sf_state = nullptr; c->d_sf_recs = nullptr; c->d_sf_data = nullptr;
+    c->sf_dirty = false;
+    if (c->sf_subs.empty()) return DABX_OK;
+    if (!c->d_gf) {                                                   // GF(2^8) tables: exp[512], log[256]
+        std::vector<uint8_t> tab(768, 0);
+        unsigned x = 1;
+        for (int i = 0; i < 255; ++i) { tab[i] = static_cast<uint8_t>(x); tab[512 + x] = static_cast<uint8_t>(i); x <<= 1; if (x & 0x100) x ^= 0x11D; }
+        for (int i = 255; i < 512; ++i) tab[i] = tab[i - 255];
+        int rc = dev_upload(c->d_gf, tab);
+        if (rc) return rc;
+    }
+    const size_t n = c->sf_subs.size();
+    int rc = dev_upload(c->d_sf_subs, c->sf_subs);
+    if (rc) return rc;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_state), n * sizeof(DevSfState)));
+    HIPCHK(hipMemset(c->d_sf_state, 0, n * sizeof(DevSfState)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_recs), static_cast<size_t>(rec) * sizeof(DevSfRec)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_data), std::max<size_t>(data, 16)));
+    return DABX_OK;
+}
+
 int64_t samples_needed(const StreamHost &s, int n_frames)
 {
     return s.st.pos + static_cast<int64_t>(n_frames + (s.st.locked ? 0 : 1)) * dabx::kTF + 4096;
@@ -273,7 +322,7 @@ void dabx_destroy(dabx_ctx *c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
-                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -301,6 +350,7 @@ int dabx_set_subchannels(dabx_ctx *c, int s, int n, const dabx_subch_t *sub)
     if (out_off > DABX_MSC_STRIDE) return DABX_E_ARG;
     auto &sh = c->streams[s];
     sh.sub.assign(sub, sub + n);
+    if (sh.dabplus) { sh.dabplus = 0; c->sf_dirty = true; }          // a new layout: the caller flags its DAB+ sub-channels again
     sh.prof = prof;
     sh.msc_bytes = out_off;
     std::copy(ds.begin(), ds.end(), c->h_sub.begin() + static_cast<size_t>(s) * 64);
@@ -424,6 +474,10 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
         int rc = build_work(c, n_frames);
         if (rc) return rc;
     }
+    if (c->sf_dirty) {
+        int rc = build_superframe_work(c);
+        if (rc) return rc;
+    }
     const DevCtx d = c->dev();
     const int S = c->cfg.n_streams;
     hipStream_t q = c->stream;
@@ -443,6 +497,9 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     else hipLaunchKernelGGL(k_demod<1>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
     if (c->n_work) hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
+    if (!c->sf_subs.empty())
+        hipLaunchKernelGGL(k_superframe, dim3(static_cast<unsigned>(c->sf_subs.size())), dim3(256), 0, q, d, c->d_sf_subs, c->d_sf_state,
+                           c->d_sf_recs, c->d_sf_data, c->d_gf, n_frames, c->sf_max_rec);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[3], q));
     hipLaunchKernelGGL(k_finish, dim3(S), dim3(256), 0, q, d, n_frames);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[4], q));
@@ -634,6 +691,54 @@ int dabx_get_null_spectrum(dabx_ctx *c, int s, float *power)
     GETTER_PROLOGUE
     if (!power || !c->d_null_spectrum) return DABX_E_ARG;
     HIPCHK(hipMemcpy(power, c->d_null_spectrum + static_cast<size_t>(s) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_set_dabplus(dabx_ctx *c, int s, uint64_t mask)
+{
+    if (!valid_stream(c, s)) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->pending) return DABX_E_ARG;
+    auto &sh = c->streams[s];
+    if (sh.sub.size() < 64 && (mask >> sh.sub.size())) return DABX_E_ARG;
+    for (size_t k = 0; k < sh.sub.size(); ++k)
+        if (((mask >> k) & 1) && (sh.prof[k].n_in % 192 || sh.prof[k].n_in > 24 * 192)) return DABX_E_PROFILE;
+    sh.dabplus = mask;
+    c->sf_dirty = true;
+    return DABX_OK;
+}
+
+static int find_sf(const dabx_ctx *c, int s, int sub)
+{
+    for (size_t i = 0; i < c->sf_subs.size(); ++i)
+        if (c->sf_subs[i].stream == s && c->sf_subs[i].sub == sub) return static_cast<int>(i);
+    return -1;
+}
+
+int dabx_get_superframes(dabx_ctx *c, int s, int sub, dabx_superframe_t *recs, uint8_t *data, int max)
+{
+    GETTER_PROLOGUE
+    if (!recs || !data || max < 0 || c->sf_dirty) return DABX_E_ARG;
+    const int i = find_sf(c, s, sub);
+    if (i < 0) return DABX_E_ARG;
+    DevSfState st;
+    HIPCHK(hipMemcpy(&st, c->d_sf_state + i, sizeof(int32_t) * 4, hipMemcpyDeviceToHost));
+    const int cnt = std::min(max, st.n_out);
+    if (cnt > 0) {
+        static_assert(sizeof(dabx_superframe_t) == sizeof(DevSfRec), "record layouts must match");
+        HIPCHK(hipMemcpy(recs, c->d_sf_recs + c->sf_subs[i].rec_off, static_cast<size_t>(cnt) * sizeof(DevSfRec), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(data, c->d_sf_data + c->sf_subs[i].data_off, static_cast<size_t>(cnt) * 110 * c->sf_subs[i].s, hipMemcpyDeviceToHost));
+    }
+    return cnt;
+}
+
+int dabx_get_superframe_stats(dabx_ctx *c, int s, int sub, uint32_t stats[6])
+{
+    GETTER_PROLOGUE
+    if (!stats || c->sf_dirty) return DABX_E_ARG;
+    const int i = find_sf(c, s, sub);
+    if (i < 0) return DABX_E_ARG;
+    HIPCHK(hipMemcpy(stats, reinterpret_cast<const uint8_t *>(c->d_sf_state + i) + offsetof(DevSfState, stats), 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return DABX_OK;
 }
 

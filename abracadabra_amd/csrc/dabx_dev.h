@@ -50,6 +50,33 @@ struct DevSub {
     int32_t out_off;    // byte offset inside the CIF's output record
 };
 
+// ---- DAB+ audio super frames (dabx_superframe.hip)
+struct DevSfSub {           // one sub-channel that carries DAB+ audio
+    int32_t stream, sub;    // sub: index into the stream's sub-channel list
+    int32_t s;              // kbps / 8 = number of RS code words per super frame
+    int32_t frame_bytes;    // 3 kbps: the sub-channel's bytes per logical frame (CIF)
+    int32_t msc_off;        // its byte offset inside a CIF record
+    uint32_t rec_off;       // first record slot of this sub-channel
+    uint32_t data_off;      // byte offset of its super frame data
+    uint32_t pad;
+};
+
+struct DevSfRec {           // = dabx_superframe_t (include/dabx.h) = dab_sf_rec_t (oracle/dab_plus.c)
+    uint32_t first_frame;
+    uint8_t header, num_aus, au_valid, au_ok;
+    uint16_t au_start[8];
+    uint16_t rs_corrected, rs_failed;
+    uint32_t pad;
+};
+
+struct DevSfState {         // persists from step to step
+    int32_t carry, synced;
+    uint32_t frames_seen;
+    int32_t n_out;          // records written by the last step
+    uint32_t stats[6];      // super frames, AUs good, AUs bad, bytes corrected, code words uncorrectable, sync losses
+    uint8_t buf[2304 + 24]; // up to four carried logical frames of 3 * 192 bytes
+};
+
 struct DevTables {
     const float2 *W;            // [2048] exp(-j 2 pi k / 2048)
     const float2 *nco_hi;       // [2048] exp(+j 2 pi k / 2^11)

@@ -1,0 +1,236 @@
+// dabx_superframe.hip — DAB+ audio super frames on the GPU (ETSI TS 102 563 §5, §6), the stage after the
+// Viterbi decoder for sub-channels that carry HE-AAC: fire code synchronisation, RS(120,110) correction
+// and access-unit CRCs for every flagged sub-channel of every stream in one launch.
+//
+// Replaces the super frame layer inside the reference's closed dabsdr library (it exports Karn's
+// init_rs_char / decode_rs_char; output contract: dabsdrAudioCBFunc_t, dabsdr.h:47-78,
+// consumer src/audiodecoder.cpp:183-208).  Oracle: oracle/dab_plus.c (dab_sf_push), same records bit for bit.
+//
+// One workgroup per (stream, sub-channel).  The logical frames of a step (the sub-channel's slice of every
+// valid CIF record k_viterbi wrote) are appended to the <= 4 frames carried over from the step before;
+// a window of five frames slides over that sequence exactly as a serial receiver would: decoded -> advance
+// by five, rejected -> advance by one.  Inside a window the work is parallel: 10 s syndromes on 10 s
+// threads, one thread per code word for the (rare) Berlekamp-Massey / Chien / Forney correction, one thread
+// per access unit for the CRC.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dabx_dev.h"
+
+namespace {
+
+struct Gf {                          // GF(2^8), p(x) = x^8 + x^4 + x^3 + x^2 + 1, tables in LDS
+    const uint8_t *exp;              // [512]
+    const uint8_t *log;              // [256]
+    __device__ uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+    __device__ uint8_t div(uint8_t a, uint8_t b) const { return a ? exp[log[a] + 255 - log[b]] : 0; }
+    __device__ uint8_t pow(int e) const { return exp[((e % 255) + 255) % 255]; }
+};
+
+// Correct one code word whose syndromes S[0..9] are not all zero.  cw(k) = sf[j + k s], k = 0 the highest
+// power.  Returns the number of corrected bytes, -1 when uncorrectable (nothing written then).
+__device__ int rs_correct(const Gf &G, uint8_t *sf, int j, int s, const uint8_t *S)
+{
+    constexpr int N = 120, T2 = 10;
+    uint8_t C[T2 + 1] = {1}, B[T2 + 1] = {1}, b = 1;
+    int L = 0, m = 1;
+    for (int n = 0; n < T2; ++n) {                       // Berlekamp-Massey
+        uint8_t d = S[n];
+        for (int i = 1; i <= L; ++i) d ^= G.mul(C[i], S[n - i]);
+        if (!d) { ++m; continue; }
+        uint8_t Tp[T2 + 1];
+        for (int i = 0; i <= T2; ++i) Tp[i] = C[i];
+        const uint8_t coef = G.div(d, b);
+        for (int i = 0; i + m <= T2; ++i) C[i + m] ^= G.mul(coef, B[i]);
+        if (2 * L <= n) {
+            L = n + 1 - L;
+            for (int i = 0; i <= T2; ++i) B[i] = Tp[i];
+            b = d; m = 1;
+        } else ++m;
+    }
+    if (L > T2 / 2) return -1;
+    int pos[T2 / 2], nerr = 0;
+    for (int k = 0; k < N; ++k) {                        // Chien search over the 120 positions of the shortened code
+        const int p = N - 1 - k;
+        uint8_t v = 0;
+        for (int i = 0; i <= L; ++i) v ^= G.mul(C[i], G.pow(-p * i));
+        if (!v) { if (nerr == T2 / 2) return -1; pos[nerr++] = k; }
+    }
+    if (nerr != L) return -1;
+    uint8_t Om[T2];
+    for (int i = 0; i < T2; ++i) {
+        uint8_t o = 0;
+        for (int q = 0; q <= L && q <= i; ++q) o ^= G.mul(S[i - q], C[q]);
+        Om[i] = o;
+    }
+    uint8_t fix[T2 / 2];
+    for (int e = 0; e < nerr; ++e) {                     // Forney, first consecutive root alpha^0
+        const int p = N - 1 - pos[e];
+        const uint8_t Xinv = G.pow(-p);
+        uint8_t num = 0, den = 0;
+        for (int i = T2 - 1; i >= 0; --i) num = static_cast<uint8_t>(G.mul(num, Xinv) ^ Om[i]);
+        for (int i = 1; i <= L; i += 2) den ^= G.mul(C[i], G.pow(-p * (i - 1)));
+        if (!den) return -1;
+        fix[e] = G.mul(G.div(num, den), G.pow(p));
+    }
+    for (int e = 0; e < nerr; ++e)
+        if (pos[e] < 110) sf[j + pos[e] * s] ^= fix[e];  // only the data part is kept (parity bytes are dropped anyway)
+    return nerr;
+}
+
+}  // namespace
+
+// max_rec: record slots per sub-channel and step
+__global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
+                                                    uint8_t *data, const uint8_t *__restrict__ gf_tab, int n_frames, int max_rec)
+{
+    __shared__ uint8_t t_exp[512], t_log[256];
+    __shared__ uint16_t t_crc[256];
+    __shared__ __attribute__((aligned(16))) uint8_t sf[2880 + 16];
+    __shared__ uint8_t synd[24 * 10];
+    __shared__ int res[24];
+    __shared__ int sh_ok, sh_num;
+    __shared__ uint16_t sh_start[8];
+    __shared__ int sh_auflag[8];
+
+    const int t = threadIdx.x;
+    const DevSfSub sb = subs[blockIdx.x];
+    DevSfState &stt = state[blockIdx.x];
+    const DevState &st = C.state[sb.stream];
+    const int s = sb.s, fb = sb.frame_bytes, sfb = 5 * fb;
+
+    for (int i = t; i < 512; i += 256) t_exp[i] = gf_tab[i];
+    t_log[t] = gf_tab[512 + t];
+    {
+        unsigned c = static_cast<unsigned>(t) << 8;
+        for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? ((c << 1) ^ 0x1021) & 0xFFFF : (c << 1) & 0xFFFF;
+        t_crc[t] = static_cast<uint16_t>(c);
+    }
+    __syncthreads();
+    const Gf G = {t_exp, t_log};
+
+    // the valid CIFs of this step are a suffix (the time de-interleaver fills at the start of a stream)
+    int first_valid = 4 * n_frames;
+    if (!st.acq_fail) {
+        const int64_t need = 15 - st.cif;
+        first_valid = need <= 0 ? 0 : (need >= 4 * n_frames ? 4 * n_frames : static_cast<int>(need));
+    }
+    const int carry = stt.carry, n_new = 4 * n_frames - first_valid, total = carry + n_new;
+    const uint32_t base = stt.frames_seen - static_cast<uint32_t>(carry);
+    const uint8_t *msc = C.msc + (size_t)sb.stream * C.max_frames * 4 * C.msc_stride + sb.msc_off;
+    auto frame_ptr = [&](int q) -> const uint8_t * {     // logical frame q of the sequence
+        return q < carry ? stt.buf + q * fb : msc + (size_t)(first_valid + q - carry) * C.msc_stride;
+    };
+
+    int i = 0, out = 0, synced = stt.synced;
+    uint32_t n_sf = 0, n_auok = 0, n_aubad = 0, n_corr = 0, n_fail = 0, n_loss = 0;      // meaningful in thread 0
+    while (i + 5 <= total) {
+        for (int f = 0; f < 5; ++f) {
+            const uint8_t *src = frame_ptr(i + f);
+            for (int b = t; b < fb; b += 256) sf[f * fb + b] = src[b];
+        }
+        __syncthreads();
+        // ---- RS(120,110): syndrome r of code word j on thread 10 j + r (Horner, highest power first)
+        if (t < 10 * s) {
+            const int j = t / 10, r = t % 10;
+            uint8_t acc = 0;
+            for (int k = 0; k < 120; ++k) {
+                if (acc) acc = t_exp[t_log[acc] + r];
+                acc ^= sf[j + k * s];
+            }
+            synd[t] = acc;
+        }
+        __syncthreads();
+        if (t < s) {
+            uint8_t S[10];
+            bool clean = true;
+            for (int r = 0; r < 10; ++r) { S[r] = synd[10 * t + r]; clean = clean && S[r] == 0; }
+            res[t] = clean ? 0 : rs_correct(G, sf, t, s, S);
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned c = 0;                               // fire code over bytes 2..10
+            for (int k = 2; k < 11; ++k) {
+                c ^= static_cast<unsigned>(sf[k]) << 8;
+                for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? ((c << 1) ^ 0x782F) & 0xFFFF : (c << 1) & 0xFFFF;
+            }
+            const bool ok = c == ((static_cast<unsigned>(sf[0]) << 8) | sf[1]) && !(sf[0] == 0 && sf[1] == 0 && sf[2] == 0);
+            sh_ok = ok;
+            if (ok) {
+                const int dac = (sf[2] >> 6) & 1, sbr = (sf[2] >> 5) & 1;
+                const int num = dac ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
+                sh_num = num;
+                sh_start[0] = static_cast<uint16_t>(dac ? (sbr ? 6 : 11) : (sbr ? 5 : 8));
+                for (int a = 1; a < num; ++a) {           // 12-bit big-endian fields packed from byte 3
+                    const int bit = 24 + 12 * (a - 1), byte = bit >> 3;
+                    sh_start[a] = static_cast<uint16_t>((bit & 4) ? (((sf[byte] & 0x0F) << 8) | sf[byte + 1]) : ((sf[byte] << 4) | (sf[byte + 1] >> 4)));
+                }
+                sh_start[num] = static_cast<uint16_t>(110 * s);
+                for (int a = num + 1; a < 8; ++a) sh_start[a] = 0;
+            }
+        }
+        __syncthreads();
+        if (!sh_ok) {                                     // not a super frame boundary (or damaged): slide by one frame
+            if (t == 0 && synced) ++n_loss;
+            synced = 0;
+            i += 1;
+            __syncthreads();
+            continue;
+        }
+        const int num = sh_num;
+        if (t < num) {                                    // one access unit per thread: bounds, then CRC-16-CCITT (inverted)
+            const int a0 = sh_start[t], a1 = sh_start[t + 1], len = a1 - a0;
+            int flag = 0;
+            if (!(a0 < sh_start[0] || len < 3 || a1 > 110 * s)) {
+                unsigned c = 0xFFFF;
+                for (int k = 0; k < len - 2; ++k) c = ((c << 8) ^ t_crc[((c >> 8) ^ sf[a0 + k]) & 0xFF]) & 0xFFFF;
+                c = ~c & 0xFFFF;
+                flag = 1 | ((c == ((static_cast<unsigned>(sf[a0 + len - 2]) << 8) | sf[a0 + len - 1])) ? 2 : 0);
+            }
+            sh_auflag[t] = flag;
+        }
+        __syncthreads();
+        if (out < max_rec) {
+            uint8_t *dst = data + sb.data_off + (size_t)out * 110 * s;
+            for (int b = t; b < 110 * s; b += 256) dst[b] = sf[b];
+        }
+        if (t == 0) {
+            DevSfRec rec = {};
+            rec.first_frame = base + static_cast<uint32_t>(i);
+            rec.header = sf[2] & 0x7F;
+            rec.num_aus = static_cast<uint8_t>(num);
+            int corrected = 0, failed = 0;
+            for (int j = 0; j < s; ++j) { if (res[j] < 0) ++failed; else corrected += res[j]; }
+            rec.rs_corrected = static_cast<uint16_t>(corrected);
+            rec.rs_failed = static_cast<uint16_t>(failed);
+            for (int a = 0; a < 8; ++a) rec.au_start[a] = sh_start[a];
+            for (int a = 0; a < num; ++a) {
+                if (sh_auflag[a] & 1) rec.au_valid |= static_cast<uint8_t>(1 << a);
+                if (sh_auflag[a] & 2) { rec.au_ok |= static_cast<uint8_t>(1 << a); ++n_auok; } else ++n_aubad;
+            }
+            if (out < max_rec) recs[sb.rec_off + out] = rec;
+            ++n_sf; n_corr += corrected; n_fail += failed;
+        }
+        ++out;
+        synced = 1;
+        i += 5;
+        __syncthreads();
+    }
+    // ---- carry the unconsumed frames (< 5) over to the next step, staged through LDS: the source may be the carry buffer itself
+    const int left = total - i;
+    for (int f = 0; f < left; ++f) {
+        const uint8_t *src = frame_ptr(i + f);
+        for (int b = t; b < fb; b += 256) sf[f * fb + b] = src[b];
+    }
+    __syncthreads();
+    for (int b = t; b < left * fb; b += 256) stt.buf[b] = sf[b];
+    if (t == 0) {
+        stt.carry = left;
+        stt.synced = synced;
+        stt.frames_seen += static_cast<uint32_t>(n_new);
+        stt.n_out = out < max_rec ? out : max_rec;
+        stt.stats[0] += n_sf; stt.stats[1] += n_auok; stt.stats[2] += n_aubad;
+        stt.stats[3] += n_corr; stt.stats[4] += n_fail; stt.stats[5] += n_loss;
+    }
+    (void)sfb;
+}

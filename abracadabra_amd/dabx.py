@@ -19,7 +19,7 @@ SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("pe
 
 # every symbol include/dabx.h declares; tests check that the library exports them all
 DABX_SYMBOLS = [
-    "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_push_all", "dabx_alloc_pinned", "dabx_free_pinned", "dabx_ring_ptr",
+    "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_push_all", "dabx_set_dabplus", "dabx_get_superframes", "dabx_get_superframe_stats", "dabx_alloc_pinned", "dabx_free_pinned", "dabx_ring_ptr",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
     "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum",
@@ -112,6 +112,10 @@ def _chk(rc):
     return rc
 
 
+SF_REC_DTYPE = np.dtype([("first_frame", "<u4"), ("header", "u1"), ("num_aus", "u1"), ("au_valid", "u1"), ("au_ok", "u1"),
+                         ("au_start", "<u2", (8,)), ("rs_corrected", "<u2"), ("rs_failed", "<u2"), ("reserved", "<u4")])   # dabx_superframe_t
+
+
 class Context:
     """A batch decoder over n_streams independent raw-IQ streams on one GPU."""
 
@@ -148,6 +152,25 @@ class Context:
     def push_pinned(self, stream, host_ptr, n_samples):
         """host_ptr: address inside a buffer from alloc_pinned(); asynchronous (see include/dabx.h)"""
         _chk(self.L.dabx_push(self.h, stream, C.c_void_p(host_ptr), n_samples, 2))
+
+    def set_dabplus(self, stream, mask):
+        """bit k of mask: the k-th sub-channel of the stream carries DAB+ audio -> super frames are decoded on the GPU"""
+        self.L.dabx_set_dabplus.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        _chk(self.L.dabx_set_dabplus(self.h, stream, mask))
+
+    def superframes(self, stream, sub, kbps, max_rec=64):
+        """records (SF_REC_DTYPE) and RS-corrected data [n, 110 * kbps/8] of the super frames the last step completed"""
+        recs = np.zeros(max_rec, dtype=SF_REC_DTYPE)
+        data = np.zeros((max_rec, 110 * (kbps // 8)), dtype=np.uint8)
+        self.L.dabx_get_superframes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        n = _chk(self.L.dabx_get_superframes(self.h, stream, sub, recs.ctypes.data, data.ctypes.data, max_rec))
+        return recs[:n].copy(), data[:n].copy()
+
+    def superframe_stats(self, stream, sub):
+        st = np.zeros(6, dtype=np.uint32)
+        self.L.dabx_get_superframe_stats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _chk(self.L.dabx_get_superframe_stats(self.h, stream, sub, st.ctypes.data))
+        return dict(zip(("superframes", "au_ok", "au_crc_err", "rs_corrected", "rs_uncorrectable", "sync_loss"), st.tolist()))
 
     def push_all(self, src_ptr, stride_bytes, n_samples, kind=2):
         """n_samples for every stream, stream s from src_ptr + s * stride_bytes (kind: 0 host, 1 device, 2 pinned)"""

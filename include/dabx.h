@@ -172,6 +172,30 @@ DABX_API int dabx_enable_spectrum(dabx_ctx *ctx, int mask);
 DABX_API int dabx_get_spectrum(dabx_ctx *ctx, int stream, float *power);
 DABX_API int dabx_get_null_spectrum(dabx_ctx *ctx, int stream, float *power);
 
+/* DAB+ audio super frames (ETSI TS 102 563): fire code synchronisation, RS(120,110) correction and access
+ * unit CRCs on the GPU for the sub-channels flagged here (bit k of mask = k-th entry of the list given to
+ * dabx_set_subchannels; what FIG 0/2 announces as ASCTy 63).  Replaces the super frame layer of the
+ * reference's library; a record is what its audio callback delivers per access unit (dabsdr.h:47-78). */
+typedef struct {
+    uint32_t first_frame;      /* index of the super frame's first logical frame among the sub-channel's valid frames */
+    uint8_t  header;           /* dabsdrAudioFrameHeader_t bits: dac_rate<<6 | sbr<<5 | aac_channel_mode<<4 | ps<<3 | mpeg_surround */
+    uint8_t  num_aus;
+    uint8_t  au_valid;         /* bit i: access unit i has sane bounds */
+    uint8_t  au_ok;            /* bit i: ... and a good CRC            */
+    uint16_t au_start[8];      /* byte offsets into the 110 * (kbps/8) data bytes; au_start[num_aus] = their count; AU i is
+                                  [au_start[i], au_start[i+1] - 2), followed by its 2 CRC bytes */
+    uint16_t rs_corrected;     /* bytes corrected by the RS decoder in this super frame */
+    uint16_t rs_failed;        /* code words it could not correct                       */
+    uint32_t reserved;
+} dabx_superframe_t;           /* 32 bytes */
+
+DABX_API int dabx_set_dabplus(dabx_ctx *ctx, int stream, uint64_t mask);
+/* Super frames completed by the last step for sub-channel `sub` of `stream`: up to max records and
+ * max * 110 * (kbps/8) data bytes (RS-corrected, parity dropped).  Returns their number. */
+DABX_API int dabx_get_superframes(dabx_ctx *ctx, int stream, int sub, dabx_superframe_t *recs, uint8_t *data, int max);
+/* running totals: super frames, AUs good, AUs bad, bytes corrected, code words uncorrectable, sync losses */
+DABX_API int dabx_get_superframe_stats(dabx_ctx *ctx, int stream, int sub, uint32_t stats[6]);
+
 /* Raw-file front end: the reference's RawFileInput accepts headerless `.raw` files and `.uff`
  * files whose first 2048 bytes hold a zero-padded XML description (reference:
  * src/input/rawfileinput.cpp:90-134, writer src/input/inputdevicerecorder.cpp:195-263).

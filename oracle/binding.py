@@ -226,3 +226,42 @@ def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0)
         assert rc == 0
         aus += data
     return out.reshape(n_superframes * 5, 24 * s), aus
+
+
+SF_REC_DTYPE = np.dtype([("first_frame", "<u4"), ("header", "u1"), ("num_aus", "u1"), ("au_valid", "u1"), ("au_ok", "u1"),
+                         ("au_start", "<u2", (8,)), ("rs_corrected", "<u2"), ("rs_failed", "<u2"), ("pad", "<u4")])
+assert SF_REC_DTYPE.itemsize == 32
+
+
+class SuperframeDecoder:
+    """oracle/dab_plus.c streaming super frame decoder (one sub-channel)"""
+
+    def __init__(self, kbps):
+        self.L = lib()
+        self.kbps, self.s = kbps, kbps // 8
+        self.state = np.zeros(4096, dtype=np.uint8)            # dab_sf_state_t, opaque
+        self.L.dab_sf_init.argtypes = [C.c_void_p, C.c_int]
+        self.L.dab_sf_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        self.L.dab_sf_init(self.state.ctypes.data, kbps)
+
+    def push(self, frames):
+        """frames: uint8 [n, 3*kbps]; returns (records, data [n_rec, 110*s])"""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, 3 * self.kbps)
+        cap = len(frames) // 5 + 2
+        recs = np.zeros(cap, dtype=SF_REC_DTYPE)
+        data = np.zeros((cap, 110 * self.s), dtype=np.uint8)
+        n = self.L.dab_sf_push(self.state.ctypes.data, frames.ctypes.data, len(frames), recs.ctypes.data, data.ctypes.data, cap)
+        return recs[:n].copy(), data[:n].copy()
+
+    def stats(self):
+        v = self.state.view(np.int32)
+        return dict(zip(("superframes", "au_ok", "au_crc_err", "rs_corrected", "rs_uncorrectable", "sync_loss"), v[4:10].tolist()),
+                    carry=int(v[2]), frames_seen=int(v[3]), synced=int(v[10]))
+
+
+def rs_decode(cw):
+    cw = np.ascontiguousarray(cw, dtype=np.uint8).copy()
+    L = lib()
+    L.dab_rs_decode_120_110.argtypes = [C.c_void_p]
+    r = L.dab_rs_decode_120_110(cw.ctypes.data)
+    return r, cw

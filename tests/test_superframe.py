@@ -52,3 +52,70 @@ def test_rs_corrects_five_byte_errors_per_codeword_and_flags_more():
     for (h, d), ref in zip(got[:n0], aus[:n0]):
         assert h == 0x70 and np.array_equal(d, ref)        # fully repaired
     assert st["au_crc_err"] >= 1 and any(h & 0x80 for h, _ in got[n0:])   # damaged AUs are flagged for concealment
+
+
+# ---- the oracle's own decoder (oracle/dab_plus.c: dab_sf_push), the checker of the GPU kernel k_superframe
+
+def _aus_of(recs, data):
+    out = []
+    for r, d in zip(recs, data):
+        for i in range(r["num_aus"]):
+            if (r["au_valid"] >> i) & 1:
+                out.append(((r["au_ok"] >> i) & 1, d[r["au_start"][i]:r["au_start"][i + 1] - 2].tobytes()))
+    return out
+
+
+@pytest.mark.parametrize("kbps,dac,sbr", [(64, 1, 1), (32, 0, 1), (96, 1, 0), (48, 0, 0), (8, 1, 1), (192, 1, 0)])
+def test_oracle_decoder_round_trip_in_pieces(kbps, dac, sbr):
+    frames, aus = ob.superframes(kbps, 5, seed=kbps + 1, dac_rate=dac, sbr=sbr)
+    lead = np.random.default_rng(2).integers(0, 256, (2, 3 * kbps), dtype=np.uint8)
+    seq = np.concatenate([lead, frames])
+    dec = ob.SuperframeDecoder(kbps)
+    recs, data = [], []
+    for a, b in ((0, 3), (3, 4), (4, 13), (13, len(seq))):          # arbitrary step boundaries: the carry must bridge them
+        r, d = dec.push(seq[a:b])
+        recs += list(r); data += list(d)
+    assert [r["first_frame"] for r in recs] == [2, 7, 12, 17, 22]
+    assert [a.tobytes() for a in aus] == [x for ok, x in _aus_of(recs, data) if ok]
+    assert dec.stats()["superframes"] == 5 and dec.stats()["au_crc_err"] == 0 and dec.stats()["carry"] == 0
+
+
+def test_oracle_decoder_agrees_with_the_host_decoder_on_damaged_input():
+    """oracle/dab_plus.c and csrc/superframe.hpp were written separately from the standard: same AUs, same statistics"""
+    kbps, s = 64, 8
+    frames, _ = ob.superframes(kbps, 6, seed=9)
+    sf = frames.reshape(6, 120 * s).copy()
+    rng = np.random.default_rng(8)
+    for j in range(s):
+        for k in rng.choice(120, 1 + j % 5, replace=False):
+            sf[1, j + k * s] ^= rng.integers(1, 256)
+    for k in rng.choice(120, 7, replace=False):
+        sf[2, 5 + k * s] ^= 0xA5                                     # uncorrectable code word
+    sf[4, 0] ^= 0xFF; sf[4, 8] ^= 0x01; sf[4, 16] ^= 0x80            # damages the fire code bytes of super frame 4 beyond... one code word, 3 errors: repaired
+    seq = np.concatenate([sf.reshape(30, 3 * kbps)[:12], np.zeros((3, 3 * kbps), np.uint8), sf.reshape(30, 3 * kbps)[12:]])   # and a gap: sync loss
+    host_aus, host_st = _decode(seq, kbps)
+    dec = ob.SuperframeDecoder(kbps)
+    recs, data = dec.push(seq)
+    orc = dec.stats()
+    assert {k: orc[k] for k in host_st} == host_st and host_st["sync_loss"] >= 1 and host_st["rs_uncorrectable"] >= 1
+    got = _aus_of(recs, data)
+    assert len(got) == len(host_aus)
+    for (ok, d), (h, hd) in zip(got, host_aus):
+        assert ok == (0 if h & 0x80 else 1) and d == hd.tobytes()
+
+
+def test_rs_decoder_corrects_up_to_five_errors():
+    rng = np.random.default_rng(4)
+    msg = rng.integers(0, 256, 110, dtype=np.uint8)
+    par = np.zeros(10, dtype=np.uint8)
+    ob.lib().dab_rs_encode_120_110(msg.ctypes.data, par.ctypes.data)
+    cw = np.concatenate([msg, par])
+    for nerr in range(0, 8):
+        bad = cw.copy()
+        for k in rng.choice(120, nerr, replace=False):
+            bad[k] ^= rng.integers(1, 256)
+        r, fixed = ob.rs_decode(bad)
+        if nerr <= 5:
+            assert r == nerr and np.array_equal(fixed, cw)
+        else:
+            assert r == -1 or not np.array_equal(fixed, cw)          # beyond the bound: detected, or (rarely) miscorrected
