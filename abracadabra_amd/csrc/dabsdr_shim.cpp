@@ -11,7 +11,6 @@
 #include "../../include/dabsdr_amd.h"
 #include "../../include/dabx.h"
 #include "fig_db.hpp"
-#include "superframe.hpp"
 #include "tii.hpp"
 
 #include <pthread.h>
@@ -70,8 +69,8 @@ struct dabsdr_s {
     uint32_t sel_sid = 0; int sel_scids = -1; bool sel_active = false;
     int sel_ascty = 0, sel_kbps = 0;
     dabsdrDecoderId_t sel_id = DABSDR_ID_AUDIO_PRIMARY;
-    dabplus::Decoder aac;                 // DAB+ super frame -> access units
-    dabplus::Stats last_stats;
+    uint32_t sf_stats[6] = {0}, last_sf_stats[6] = {0};   // k_superframe totals: super frames, AUs good/bad, RS corrected/uncorrectable, sync losses
+    std::vector<uint8_t> sf_data;
     uint32_t audio_bytes_acc = 0;
     std::vector<figdb::UserApp> app_snapshot;
     bool spectrum_on = false, tii_on = false;
@@ -298,8 +297,9 @@ void handle_request(dabsdr_s *h, const Request &r)
                     h->sel_sid = r.a; h->sel_scids = r.b; h->sel_active = true;
                     h->sel_ascty = c.ascty_dscty; h->sel_kbps = it->second.kbps;
                     h->sel_id = static_cast<dabsdrDecoderId_t>(r.c);
-                    h->aac.configure(h->sel_kbps);
-                    h->last_stats = dabplus::Stats();
+                    if (h->sel_ascty == 63 && dabx_set_dabplus(h->ctx, 0, 1) != DABX_OK) h->sel_ascty = -1;   // DAB+: super frames on the GPU
+                    std::memset(h->sf_stats, 0, sizeof h->sf_stats);
+                    std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
                 }
                 break;
             }
@@ -435,29 +435,41 @@ void after_step(dabsdr_s *h)
             }
         }
     }
-    // selected audio service: the CIF's decoded sub-channel bytes -> access units -> audio callback
+    // selected audio service -> audio callback (dabsdr.h:47-78): DAB+ access units come from k_superframe's records
+    // (a damaged unit keeps its place with the conceal bit set, as audiodecoder.cpp:183-208 expects), MPEG Layer II
+    // sub-channels are handed over one logical frame at a time
     if (h->sel_active && h->audio_cb && h->sel_kbps > 0) {
-        std::vector<uint8_t> msc(4 * static_cast<size_t>(3 * h->sel_kbps));
-        uint8_t valid[4];
-        if (dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK) {
-            for (int c = 0; c < 4; ++c) {
-                if (!valid[c]) continue;
-                const uint8_t *frame = msc.data() + static_cast<size_t>(c) * 3 * h->sel_kbps;
-                if (h->sel_ascty == 63) {                  // DAB+ (HE-AAC): super frames
-                    h->aac.push(frame, [&](const dabplus::AccessUnit &au) {
-                        dabsdrAudioCBData_t d;
-                        d.id = h->sel_id; d.ASCTy = 63; d.header.raw = au.header; d.auLen = au.len; d.pAuData = au.data;
-                        h->audio_bytes_acc += au.len;
-                        h->audio_cb(&d, h->audio_ctx);
-                    });
-                } else {                                   // MPEG-1/2 Layer II: one logical frame per call
+        if (h->sel_ascty == 63) {
+            const int s8 = h->sel_kbps / 8;
+            dabx_superframe_t recs[2];
+            h->sf_data.resize(2 * 110 * static_cast<size_t>(s8));
+            const int n = dabx_get_superframes(h->ctx, 0, 0, recs, h->sf_data.data(), 2);
+            for (int k = 0; k < n; ++k) {
+                const uint8_t *base = h->sf_data.data() + static_cast<size_t>(k) * 110 * s8;
+                for (int a = 0; a < recs[k].num_aus; ++a) {
+                    if (!((recs[k].au_valid >> a) & 1)) continue;
                     dabsdrAudioCBData_t d;
-                    d.id = h->sel_id; d.ASCTy = static_cast<uint8_t>(h->sel_ascty); d.header.raw = 0;
-                    d.auLen = static_cast<uint16_t>(3 * h->sel_kbps); d.pAuData = frame;
+                    d.id = h->sel_id; d.ASCTy = 63;
+                    d.header.raw = static_cast<uint8_t>(recs[k].header | (((recs[k].au_ok >> a) & 1) ? 0 : 0x80));
+                    d.auLen = static_cast<uint16_t>(recs[k].au_start[a + 1] - recs[k].au_start[a] - 2);
+                    d.pAuData = base + recs[k].au_start[a];
                     h->audio_bytes_acc += d.auLen;
                     h->audio_cb(&d, h->audio_ctx);
                 }
             }
+            if (n >= 0) dabx_get_superframe_stats(h->ctx, 0, 0, h->sf_stats);
+        } else if (h->sel_ascty >= 0) {
+            std::vector<uint8_t> msc(4 * static_cast<size_t>(3 * h->sel_kbps));
+            uint8_t valid[4];
+            if (dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK)
+                for (int c = 0; c < 4; ++c) {
+                    if (!valid[c]) continue;
+                    dabsdrAudioCBData_t d;
+                    d.id = h->sel_id; d.ASCTy = static_cast<uint8_t>(h->sel_ascty); d.header.raw = 0;
+                    d.auLen = static_cast<uint16_t>(3 * h->sel_kbps); d.pAuData = msc.data() + static_cast<size_t>(c) * 3 * h->sel_kbps;
+                    h->audio_bytes_acc += d.auLen;
+                    h->audio_cb(&d, h->audio_ctx);
+                }
         }
     }
     if (h->period_log2 >= 0 && ++h->period_frames >= (1 << h->period_log2)) {
@@ -472,14 +484,15 @@ void after_step(dabsdr_s *h)
             p.secMsec = static_cast<uint16_t>((h->db.ens.seconds << 10) | h->db.ens.ms);
         }
         p.fibErrorCntr = static_cast<uint16_t>(h->fib_err_acc);
-        const dabplus::Stats &now = h->aac.stats;
-        p.mscCrcOkCntr = static_cast<uint8_t>(now.au_ok - h->last_stats.au_ok);
-        p.mscCrcErrorCntr = static_cast<uint8_t>(now.au_crc_err - h->last_stats.au_crc_err);
-        p.rsUncorrectableCntr = static_cast<uint16_t>(now.rs_uncorrectable - h->last_stats.rs_uncorrectable);
-        p.rsBitErrors = static_cast<uint16_t>(now.rs_corrected - h->last_stats.rs_corrected);
-        p.rsBytes = static_cast<uint16_t>((now.superframes - h->last_stats.superframes) * 120u * static_cast<unsigned>(h->sel_kbps / 8));
+        const uint32_t *now = h->sf_stats, *was = h->last_sf_stats;
+        p.mscCrcOkCntr = static_cast<uint8_t>(now[1] - was[1]);
+        p.mscCrcErrorCntr = static_cast<uint8_t>(now[2] - was[2]);
+        p.rsUncorrectableCntr = static_cast<uint16_t>(now[4] - was[4]);
+        p.rsBitErrors = static_cast<uint16_t>(now[3] - was[3]);
+        p.rsBytes = static_cast<uint16_t>((now[0] - was[0]) * 120u * static_cast<unsigned>(h->sel_kbps / 8));
         p.audioServiceBytes = static_cast<uint16_t>(h->audio_bytes_acc);
-        h->last_stats = now; h->audio_bytes_acc = 0;
+        std::memcpy(h->last_sf_stats, h->sf_stats, sizeof h->sf_stats);
+        h->audio_bytes_acc = 0;
         notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, &p, sizeof p);
         h->period_frames = 0; h->fib_err_acc = 0;
     }
@@ -616,28 +629,6 @@ DABSDR_API int dabsdr_amd_tii_detect(const float *power, float factor, uint8_t *
         ids[2 * n] = id.main; ids[2 * n + 1] = id.sub; ++n;
     }
     return n;
-}
-
-// test hook (CPU only): run logical frames of a DAB+ sub-channel through the super frame decoder.
-// out receives records {header, len lo, len hi, data[len]}; stats[6] = superframes, au_ok,
-// au_crc_err, rs_corrected, rs_uncorrectable, sync_loss.  Returns bytes written or -1.
-DABSDR_API int dabsdr_amd_superframe_decode(const uint8_t *frames, int n_frames, int kbps, uint8_t *out, int cap, uint32_t *stats)
-{
-    dabplus::Decoder dec(kbps);
-    int used = 0;
-    bool overflow = false;
-    for (int f = 0; f < n_frames; ++f)
-        dec.push(frames + static_cast<size_t>(f) * 3 * kbps, [&](const dabplus::AccessUnit &au) {
-            if (used + 3 + au.len > cap) { overflow = true; return; }
-            out[used++] = au.header; out[used++] = static_cast<uint8_t>(au.len); out[used++] = static_cast<uint8_t>(au.len >> 8);
-            std::memcpy(out + used, au.data, au.len);
-            used += au.len;
-        });
-    if (stats) {
-        stats[0] = dec.stats.superframes; stats[1] = dec.stats.au_ok; stats[2] = dec.stats.au_crc_err;
-        stats[3] = dec.stats.rs_corrected; stats[4] = dec.stats.rs_uncorrectable; stats[5] = dec.stats.sync_loss;
-    }
-    return overflow ? -1 : used;
 }
 
 // test hook (CPU only): parse FIBs and print the ensemble as text, see tests/test_figdb.py

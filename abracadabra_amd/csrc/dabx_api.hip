@@ -497,8 +497,9 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     else hipLaunchKernelGGL(k_demod<1>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
     if (c->n_work) hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[5], q));
     if (!c->sf_subs.empty())
-        hipLaunchKernelGGL(k_superframe, dim3(static_cast<unsigned>(c->sf_subs.size())), dim3(256), 0, q, d, c->d_sf_subs, c->d_sf_state,
+        hipLaunchKernelGGL(k_superframe, dim3(static_cast<unsigned>(c->sf_subs.size())), dim3(SF_THREADS), 0, q, d, c->d_sf_subs, c->d_sf_state,
                            c->d_sf_recs, c->d_sf_data, c->d_gf, n_frames, c->sf_max_rec);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[3], q));
     hipLaunchKernelGGL(k_finish, dim3(S), dim3(256), 0, q, d, n_frames);
@@ -518,7 +519,10 @@ int dabx_wait(dabx_ctx *c)
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int s = 0; s < c->cfg.n_streams; ++s) c->streams[s].st = c->h_state[s];
     if (c->timing) {
-        for (int i = 0; i < 4; ++i) HIPCHK(hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
+        HIPCHK(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));
+        HIPCHK(hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
+        HIPCHK(hipEventElapsedTime(&c->last_ms[2], c->ev[2], c->ev[5]));      // k_viterbi alone
+        HIPCHK(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[4]));      // k_superframe (if any) + k_finish
         HIPCHK(hipEventElapsedTime(&c->last_ms[4], c->ev[0], c->ev[4]));
     }
     c->pending = false;

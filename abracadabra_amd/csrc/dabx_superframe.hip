@@ -19,6 +19,9 @@
 
 namespace {
 
+constexpr int CRC_CHUNK = 32;
+constexpr int SF_THREADS = 128;      // two waves: at most 96 chunks / 10 s syndromes are in flight at once, and more workgroups fit a CU
+
 struct Gf {                          // GF(2^8), p(x) = x^8 + x^4 + x^3 + x^2 + 1, tables in LDS
     const uint8_t *exp;              // [512]
     const uint8_t *log;              // [256]
@@ -81,11 +84,13 @@ __device__ int rs_correct(const Gf &G, uint8_t *sf, int j, int s, const uint8_t 
 }  // namespace
 
 // max_rec: record slots per sub-channel and step
-__global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
+__global__ __launch_bounds__(SF_THREADS) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
                                                     uint8_t *data, const uint8_t *__restrict__ gf_tab, int n_frames, int max_rec)
 {
     __shared__ uint8_t t_exp[512], t_log[256];
-    __shared__ uint16_t t_crc[256];
+    __shared__ uint16_t t_crc[256], t_fire[256], t_shift[16];
+    __shared__ uint16_t ch_crc[96];                      // CRC of every 32-byte chunk of the access units
+    __shared__ int16_t ch_first[8];                      // first chunk of access unit a (ch_first[num] = total)
     __shared__ __attribute__((aligned(16))) uint8_t sf[2880 + 16];
     __shared__ uint8_t synd[24 * 10];
     __shared__ int res[24];
@@ -99,12 +104,22 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
     const DevState &st = C.state[sb.stream];
     const int s = sb.s, fb = sb.frame_bytes, sfb = 5 * fb;
 
-    for (int i = t; i < 512; i += 256) t_exp[i] = gf_tab[i];
-    t_log[t] = gf_tab[512 + t];
-    {
-        unsigned c = static_cast<unsigned>(t) << 8;
-        for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? ((c << 1) ^ 0x1021) & 0xFFFF : (c << 1) & 0xFFFF;
-        t_crc[t] = static_cast<uint16_t>(c);
+    for (int i = t; i < 512; i += SF_THREADS) t_exp[i] = gf_tab[i];
+    for (int v = t; v < 256; v += SF_THREADS) {
+        t_log[v] = gf_tab[512 + v];
+        unsigned c = static_cast<unsigned>(v) << 8, f = c;
+        for (int b = 0; b < 8; ++b) {
+            c = (c & 0x8000) ? ((c << 1) ^ 0x1021) & 0xFFFF : (c << 1) & 0xFFFF;
+            f = (f & 0x8000) ? ((f << 1) ^ 0x782F) & 0xFFFF : (f << 1) & 0xFFFF;
+        }
+        t_crc[v] = static_cast<uint16_t>(c);
+        t_fire[v] = static_cast<uint16_t>(f);
+    }
+    __syncthreads();
+    if (t < 16) {                                        // x^t * x^(8*32) mod the CRC polynomial: moves a CRC past a 32-byte chunk
+        unsigned c = 1u << t;
+        for (int k = 0; k < CRC_CHUNK; ++k) c = ((c << 8) ^ t_crc[(c >> 8) & 0xFF]) & 0xFFFF;
+        t_shift[t] = static_cast<uint16_t>(c);
     }
     __syncthreads();
     const Gf G = {t_exp, t_log};
@@ -125,20 +140,36 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
     int i = 0, out = 0, synced = stt.synced;
     uint32_t n_sf = 0, n_auok = 0, n_aubad = 0, n_corr = 0, n_fail = 0, n_loss = 0;      // meaningful in thread 0
     while (i + 5 <= total) {
-        for (int f = 0; f < 5; ++f) {
-            const uint8_t *src = frame_ptr(i + f);
-            for (int b = t; b < fb; b += 256) sf[f * fb + b] = src[b];
+        {   // the window as 32-bit words (frames are multiples of 24 bytes): up to six loads in flight per thread
+            const int wpf = fb >> 2, nw = 5 * wpf;
+            uint32_t w[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = t + SF_THREADS * u;
+                if (idx < nw) {
+                    const int f = idx / wpf, o = idx - f * wpf;
+                    w[u] = reinterpret_cast<const uint32_t *>(frame_ptr(i + f))[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+                if (t + SF_THREADS * u < nw) reinterpret_cast<uint32_t *>(sf)[t + SF_THREADS * u] = w[u];
         }
         __syncthreads();
-        // ---- RS(120,110): syndrome r of code word j on thread 10 j + r (Horner, highest power first)
-        if (t < 10 * s) {
-            const int j = t / 10, r = t % 10;
-            uint8_t acc = 0;
-            for (int k = 0; k < 120; ++k) {
-                if (acc) acc = t_exp[t_log[acc] + r];
-                acc ^= sf[j + k * s];
+        // ---- RS(120,110): syndrome r of code word j is item 10 j + r
+        for (int q = t; q < 10 * s; q += SF_THREADS) {
+            // S_r = sum_k c_k alpha^(r (119 - k)): 120 independent table look-ups instead of a Horner chain
+            const int j = q / 10, r = q % 10;
+            unsigned acc = 0;
+            int e = (r * 119) % 255;
+#pragma unroll 8
+            for (int k = 0; k < 120; ++k) {              // branch-free so that the look-ups of several terms overlap
+                const unsigned cb = sf[j + k * s];
+                acc ^= cb ? t_exp[t_log[cb] + e] : 0u;
+                e -= r;
+                e += e < 0 ? 255 : 0;
             }
-            synd[t] = acc;
+            synd[q] = static_cast<uint8_t>(acc);
         }
         __syncthreads();
         if (t < s) {
@@ -150,10 +181,7 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
         __syncthreads();
         if (t == 0) {
             unsigned c = 0;                               // fire code over bytes 2..10
-            for (int k = 2; k < 11; ++k) {
-                c ^= static_cast<unsigned>(sf[k]) << 8;
-                for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? ((c << 1) ^ 0x782F) & 0xFFFF : (c << 1) & 0xFFFF;
-            }
+            for (int k = 2; k < 11; ++k) c = ((c << 8) ^ t_fire[((c >> 8) ^ sf[k]) & 0xFF]) & 0xFFFF;
             const bool ok = c == ((static_cast<unsigned>(sf[0]) << 8) | sf[1]) && !(sf[0] == 0 && sf[1] == 0 && sf[2] == 0);
             sh_ok = ok;
             if (ok) {
@@ -167,6 +195,13 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
                 }
                 sh_start[num] = static_cast<uint16_t>(110 * s);
                 for (int a = num + 1; a < 8; ++a) sh_start[a] = 0;
+                int nch = 0;                              // chunks of the access units with sane bounds
+                for (int a = 0; a < num; ++a) {
+                    ch_first[a] = static_cast<int16_t>(nch);
+                    const int a0 = sh_start[a], a1 = sh_start[a + 1], len = a1 - a0;
+                    if (!(a0 < sh_start[0] || len < 3 || a1 > 110 * s)) nch += (len - 2 + CRC_CHUNK - 1) / CRC_CHUNK;
+                }
+                ch_first[num] = static_cast<int16_t>(nch);
             }
         }
         __syncthreads();
@@ -178,12 +213,30 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
             continue;
         }
         const int num = sh_num;
-        if (t < num) {                                    // one access unit per thread: bounds, then CRC-16-CCITT (inverted)
+        // CRC-16-CCITT of the access units in 32-byte chunks, one thread per chunk: the FIRST chunk of a unit is the
+        // short one and starts from 0xFFFF, the others are whole and start from 0, so joining them is
+        // crc = shift32(crc) ^ crc(chunk) with shift32 = a 16-entry table (the CRC is linear over GF(2))
+        if (t < ch_first[num]) {
+            int a = 0;
+            while (t >= ch_first[a + 1]) ++a;
+            const int a0 = sh_start[a], n = sh_start[a + 1] - a0 - 2, nch = ch_first[a + 1] - ch_first[a], q = t - ch_first[a];
+            const int first_len = n - (nch - 1) * CRC_CHUNK;
+            const int beg = q == 0 ? 0 : first_len + (q - 1) * CRC_CHUNK, cnt = q == 0 ? first_len : CRC_CHUNK;
+            unsigned c = q == 0 ? 0xFFFFu : 0u;
+            for (int k = 0; k < cnt; ++k) c = ((c << 8) ^ t_crc[((c >> 8) ^ sf[a0 + beg + k]) & 0xFF]) & 0xFFFF;
+            ch_crc[t] = static_cast<uint16_t>(c);
+        }
+        __syncthreads();
+        if (t < num) {                                    // one access unit per thread: bounds, then join its chunks
             const int a0 = sh_start[t], a1 = sh_start[t + 1], len = a1 - a0;
             int flag = 0;
             if (!(a0 < sh_start[0] || len < 3 || a1 > 110 * s)) {
-                unsigned c = 0xFFFF;
-                for (int k = 0; k < len - 2; ++k) c = ((c << 8) ^ t_crc[((c >> 8) ^ sf[a0 + k]) & 0xFF]) & 0xFFFF;
+                unsigned c = ch_crc[ch_first[t]];
+                for (int q = ch_first[t] + 1; q < ch_first[t + 1]; ++q) {
+                    unsigned m = 0;
+                    for (int b = 0; b < 16; ++b) m ^= ((c >> b) & 1u) ? t_shift[b] : 0u;
+                    c = m ^ ch_crc[q];
+                }
                 c = ~c & 0xFFFF;
                 flag = 1 | ((c == ((static_cast<unsigned>(sf[a0 + len - 2]) << 8) | sf[a0 + len - 1])) ? 2 : 0);
             }
@@ -192,7 +245,7 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
         __syncthreads();
         if (out < max_rec) {
             uint8_t *dst = data + sb.data_off + (size_t)out * 110 * s;
-            for (int b = t; b < 110 * s; b += 256) dst[b] = sf[b];
+            for (int b = t; b < 110 * s; b += SF_THREADS) dst[b] = sf[b];
         }
         if (t == 0) {
             DevSfRec rec = {};
@@ -220,10 +273,10 @@ __global__ __launch_bounds__(256) void k_superframe(DevCtx C, const DevSfSub *__
     const int left = total - i;
     for (int f = 0; f < left; ++f) {
         const uint8_t *src = frame_ptr(i + f);
-        for (int b = t; b < fb; b += 256) sf[f * fb + b] = src[b];
+        for (int b = t; b < fb; b += SF_THREADS) sf[f * fb + b] = src[b];
     }
     __syncthreads();
-    for (int b = t; b < left * fb; b += 256) stt.buf[b] = sf[b];
+    for (int b = t; b < left * fb; b += SF_THREADS) stt.buf[b] = sf[b];
     if (t == 0) {
         stt.carry = left;
         stt.synced = synced;

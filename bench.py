@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--nsub", type=int, default=18, help="48-CU EEP 3-A sub-channels per ensemble (18 = all 864 CU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-fed (PCIe-inclusive) side measurement")
+    ap.add_argument("--dabplus", action="store_true",
+                    help="side measurement: every sub-channel carries DAB+ super frames and k_superframe decodes them "
+                         "(period 20 frames = 16 super frames per sub-channel; not the headline workload)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
     ap.add_argument("--cpu-frames", type=int, default=208)
@@ -59,8 +62,12 @@ def make_stream(args, rank, s, sub):
     from oracle import binding as ob          # synthetic transmitter lives with the test infrastructure
     gid = rank * args.streams + s
     rng = np.random.default_rng(1000 + gid)
+    payload = None
+    if args.dabplus:                           # 4 P logical frames = whole super frames, so the periodic signal stays in sync
+        assert (4 * args.period) % 5 == 0
+        payload = np.concatenate([ob.superframes(sc[3], 4 * args.period // 5, seed=7 * gid + k)[0] for k, sc in enumerate(sub)], axis=1)
     iq, fib, msc = ob.tx_generate(seed=5000 + gid, eid=0x1000 + (gid & 0xFFF), n_frames=args.period, subch=sub, delay=0,
-                                  loop=1, fmt=0, snr_db=args.snr, cfo_hz=float(rng.uniform(-3000.0, 3000.0)), rms=28.0)
+                                  loop=1, fmt=0, snr_db=args.snr, cfo_hz=float(rng.uniform(-3000.0, 3000.0)), rms=28.0, payload=payload)
     shift = int(rng.integers(0, TF))           # arbitrary start position inside the frame
     iq = np.roll(iq.reshape(-1, 2), shift, axis=0).reshape(-1)
     return iq, fib, msc, shift
@@ -122,6 +129,8 @@ def main():
     import abracadabra_amd as aa
     from oracle import binding as ob
     sub = ob.subch_layout(args.nsub, 64)        # default: all 864 CU = 18 x 48 CU, EEP 3-A, 64 kbit/s
+    if args.dabplus:
+        args.period = 20
     S, F, P = args.streams, args.frames, args.period
     assert P % 4 == 0 and P >= F + 2
 
@@ -135,6 +144,8 @@ def main():
         ctx.set_subchannels(s, sub)
         ctx.push(s, iq)                          # fills the ring exactly once: the signal is periodic
         ctx.set_write_pos(s, 1 << 62)            # resident periodic ring: never underruns
+        if args.dabplus:
+            ctx.set_dabplus(s, (1 << len(sub)) - 1)
     ctx.enable_timing(True)
 
     def barrier():
@@ -172,6 +183,16 @@ def main():
                 if gv[f, c]:
                     checked += 1
                     mism += (gm[f, c].tobytes() not in msc_set)
+
+    dabplus = None
+    if args.dabplus:                             # what k_superframe made of the sub-channels of a few streams
+        tot = {}
+        for s in range(0, S, max(1, S // 8)):
+            for k in range(len(sub)):
+                for key, v in ctx.superframe_stats(s, k).items():
+                    tot[key] = tot.get(key, 0) + v
+        dabplus = {"stats_of_sampled_subchannels": tot, "post_viterbi_ms_per_step": round(float(phase_ms[3]) / args.steps, 3),
+                   "superframes_per_step": S * len(sub) * 4 * F // 5}
 
     # ---- the same step fed through the host boundary, reported beside `value`, never as `value` (the inputs of
     # the timed region above are resident): (a) dabx_push from pageable numpy arrays, synchronous; (b) from
@@ -280,6 +301,8 @@ def main():
                          "chain_algorithmic_GBps": round(value / world / FRAME_S * BYTES_CHAIN / 1e9, 2)},
             "setup_s": {"synthesis": round(t_gen, 1)},
         }
+        if args.dabplus:
+            out["dabplus"] = dabplus
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:

@@ -212,7 +212,7 @@ typedef struct {
 DABX_API int dabx_rawfile_probe(const uint8_t *head, int n_bytes, dabx_rawfile_info_t *info);
 
 /* Timing of the last step, HIP events on the context's stream (ms):
- * [0] acquire+sync, [1] FFT/demap, [2] Viterbi, [3] CRC/state, [4] whole step */
+ * [0] acquire+sync, [1] FFT/demap, [2] Viterbi, [3] super frames + CRC/state, [4] whole step */
 DABX_API int dabx_last_timing(dabx_ctx *ctx, float ms[5]);
 DABX_API int dabx_enable_timing(dabx_ctx *ctx, int on);
 
