@@ -11,6 +11,7 @@
 #include "../../include/dabsdr_amd.h"
 #include "../../include/dabx.h"
 #include "fig_db.hpp"
+#include "pad.hpp"
 #include "tii.hpp"
 
 #include <pthread.h>
@@ -71,8 +72,9 @@ struct dabsdr_s {
     dabsdrDecoderId_t sel_id = DABSDR_ID_AUDIO_PRIMARY;
     uint32_t sf_stats[6] = {0}, last_sf_stats[6] = {0};   // k_superframe totals: super frames, AUs good/bad, RS corrected/uncorrectable, sync losses
     std::vector<uint8_t> sf_data;
+    pad::Decoder pad;                     // X-PAD of the selected DAB+ service -> dynamic label / data group callbacks
     uint32_t audio_bytes_acc = 0;
-    std::vector<figdb::UserApp> app_snapshot;
+    std::vector<figdb::UserApp> app_snapshot, sel_apps;
     bool spectrum_on = false, tii_on = false;
     int tii_mode = DABSDR_TII_MODE_DEFAULT;
     std::vector<float> spectrum, null_power;
@@ -298,6 +300,8 @@ void handle_request(dabsdr_s *h, const Request &r)
                     h->sel_ascty = c.ascty_dscty; h->sel_kbps = it->second.kbps;
                     h->sel_id = static_cast<dabsdrDecoderId_t>(r.c);
                     if (h->sel_ascty == 63 && dabx_set_dabplus(h->ctx, 0, 1) != DABX_OK) h->sel_ascty = -1;   // DAB+: super frames on the GPU
+                    h->pad.reset();
+                    h->sel_apps = c.apps;
                     std::memset(h->sf_stats, 0, sizeof h->sf_stats);
                     std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
                 }
@@ -455,6 +459,7 @@ void after_step(dabsdr_s *h)
                     d.pAuData = base + recs[k].au_start[a];
                     h->audio_bytes_acc += d.auLen;
                     h->audio_cb(&d, h->audio_ctx);
+                    if ((recs[k].au_ok >> a) & 1) h->pad.feed_dabplus_au(d.pAuData, d.auLen);
                 }
             }
             if (n >= 0) dabx_get_superframe_stats(h->ctx, 0, 0, h->sf_stats);
@@ -562,6 +567,19 @@ uint8_t dabsdrInit(dabsdrHandle_t *handle)
         return EXIT_FAILURE;
     }
     dabx_enable_spectrum(h->ctx, 2);                 // null-symbol spectrum: noise estimate and TII
+    h->pad.on_dynamic_label = [h](const uint8_t *d, int n) {
+        if (!h->dl_cb) return;
+        dabsdrDynamicLabelCBData_t cb = {h->sel_id, static_cast<uint16_t>(n), d};
+        h->dl_cb(&cb, h->dl_ctx);
+    };
+    h->pad.on_data_group = [h](int xpad_app, const uint8_t *d, int n) {
+        if (!h->dg_cb) return;
+        uint16_t type = xpad_app == 12 ? 0x002 : 0;                   // default: MOT slide show; else what FIG 0/13 announces
+        for (const auto &a : h->sel_apps)
+            if (!a.data.empty() && (a.data[0] & 0x1F) == xpad_app) type = static_cast<uint16_t>(a.type);
+        dabsdrDataGroupCBData_t cb = {h->sel_id, 0, type, static_cast<uint16_t>(n), d};
+        h->dg_cb(&cb, h->dg_ctx);
+    };
     *handle = h;
     return EXIT_SUCCESS;
 }
@@ -629,6 +647,32 @@ DABSDR_API int dabsdr_amd_tii_detect(const float *power, float factor, uint8_t *
         ids[2 * n] = id.main; ids[2 * n + 1] = id.sub; ++n;
     }
     return n;
+}
+
+// test hook (CPU only): feed DAB+ access units (len lo, len hi, bytes; concatenated) to the PAD decoder; out receives the
+// dynamic-label segments and data groups as records {kind 'L' | 'G', app type, len lo, len hi, bytes}
+DABSDR_API int dabsdr_amd_pad_decode(const uint8_t *aus, int n_bytes, uint8_t *out, int cap, uint32_t *stats)
+{
+    pad::Decoder dec;
+    int used = 0;
+    bool overflow = false;
+    auto emit = [&](char kind, int app, const uint8_t *d, int n) {
+        if (used + 4 + n > cap) { overflow = true; return; }
+        out[used] = static_cast<uint8_t>(kind); out[used + 1] = static_cast<uint8_t>(app);
+        out[used + 2] = static_cast<uint8_t>(n & 0xFF); out[used + 3] = static_cast<uint8_t>(n >> 8);
+        std::memcpy(out + used + 4, d, static_cast<size_t>(n));
+        used += 4 + n;
+    };
+    dec.on_dynamic_label = [&](const uint8_t *d, int n) { emit('L', 2, d, n); };
+    dec.on_data_group = [&](int app, const uint8_t *d, int n) { emit('G', app, d, n); };
+    for (int pos = 0; pos + 2 <= n_bytes;) {
+        const int len = aus[pos] | (aus[pos + 1] << 8);
+        if (pos + 2 + len > n_bytes) break;
+        dec.feed_dabplus_au(aus + pos + 2, len);
+        pos += 2 + len;
+    }
+    if (stats) { stats[0] = dec.stats.pads; stats[1] = dec.stats.dl_ok; stats[2] = dec.stats.dl_crc_err; stats[3] = dec.stats.dg_ok; stats[4] = dec.stats.dg_crc_err; }
+    return overflow ? -1 : used;
 }
 
 // test hook (CPU only): parse FIBs and print the ensemble as text, see tests/test_figdb.py

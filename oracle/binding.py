@@ -205,8 +205,10 @@ def decode_linear(soft, kind=0, option=0, level=3, kbps=64):
     return out[:n].copy()
 
 
-def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0):
+def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0, au_heads=None):
     """Random DAB+ audio super frames for a kbps sub-channel.
+    au_heads: optional list of byte strings; access unit i starts with au_heads[i] (e.g. a data_stream_element
+    carrying PAD), the rest of it is random.
     Returns (bytes [n_superframes*5, 3*kbps] = one row per logical frame, list of AU payloads)."""
     L = lib()
     s = kbps // 8
@@ -219,7 +221,19 @@ def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0)
     for f in range(n_superframes):
         cuts = np.sort(rng.choice(np.arange(8, room - 8), num_aus - 1, replace=False)) if num_aus > 1 else np.array([], dtype=int)
         lens = np.diff(np.concatenate([[0], cuts, [room]])).astype(np.int32)
+        while au_heads is not None and num_aus > 1 and lens.min() < 40:         # room for the prescribed heads
+            cuts = np.sort(rng.choice(np.arange(8, room - 8), num_aus - 1, replace=False))
+            lens = np.diff(np.concatenate([[0], cuts, [room]])).astype(np.int32)
         data = [rng.integers(0, 256, int(n), dtype=np.uint8) for n in lens]
+        if au_heads is not None:
+            for d in data:
+                k = len(aus) + next(i for i, x in enumerate(data) if x is d)
+                if k < len(au_heads):
+                    h = np.frombuffer(au_heads[k], dtype=np.uint8)
+                    assert len(h) <= len(d)
+                    d[:len(h)] = h
+                else:
+                    d[0] &= 0x1F                                               # not a data_stream_element
         ptrs = (C.c_void_p * num_aus)(*[d.ctypes.data for d in data])
         ln = (C.c_int * num_aus)(*[int(n) for n in lens])
         rc = L.dab_superframe_build(s, dac_rate, sbr, ch_mode, ps, 0, ptrs, ln, out[f].ctypes.data)

@@ -247,7 +247,14 @@ def test_service_selection_delivers_dabplus_access_units():
     L = aa.load_library()
     sub = [[0, 0, 3, 64], [48, 1, 4, 32]]
     n_frames = 30
-    sf_rows, aus_tx = ob.superframes(64, n_frames * 4 // 5, seed=11)
+    # every access unit starts with a data_stream_element whose X-PAD carries a dynamic label (three segments, repeated)
+    from tests.test_pad import au as pad_au, dl_groups, spread, xpad_var
+    dl_text = "GRAFT FM: super frames, Reed-Solomon and PAD on an MI355X"
+    heads = []
+    for rep in range(8):
+        for g in dl_groups(dl_text, toggle=rep & 1):
+            heads += [pad_au(xpad_var([sub]), filler=b"") for sub in spread(g, 2, 8)]
+    sf_rows, aus_tx = ob.superframes(64, n_frames * 4 // 5, seed=11, au_heads=heads)
     payload = np.zeros((n_frames * 4, 192 + 96), dtype=np.uint8)
     payload[:len(sf_rows), :192] = sf_rows
     payload[:, 192:] = np.random.default_rng(2).integers(0, 256, (n_frames * 4, 96), dtype=np.uint8)
@@ -275,6 +282,17 @@ def test_service_selection_delivers_dabplus_access_units():
         with lock:
             events.append((p.contents.nid, p.contents.status))
 
+    class DlCB(C.Structure):
+        _fields_ = [("id", C.c_int), ("len", C.c_uint16), ("pData", C.POINTER(C.c_uint8))]
+
+    labels = []
+
+    @C.CFUNCTYPE(None, C.POINTER(DlCB), C.c_void_p)
+    def on_dl(p, ctx):
+        d = p.contents
+        with lock:
+            labels.append(bytes(np.ctypeslib.as_array(d.pData, shape=(d.len,))))
+
     @C.CFUNCTYPE(None, C.POINTER(AudioCB), C.c_void_p)
     def on_audio(p, ctx):
         a = p.contents
@@ -286,7 +304,7 @@ def test_service_selection_delivers_dabplus_access_units():
     for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         getattr(L, name)(handle, C.cast(get_samples, C.c_void_p))
-    for name, fn in (("dabsdrRegisterNotificationCb", on_ntf), ("dabsdrRegisterAudioCb", on_audio)):
+    for name, fn in (("dabsdrRegisterNotificationCb", on_ntf), ("dabsdrRegisterAudioCb", on_audio), ("dabsdrRegisterDynamicLabelCb", on_dl)):
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         getattr(L, name)(handle, C.cast(fn, C.c_void_p), None)
     L.dabsdr.argtypes = [C.c_void_p]
@@ -321,3 +339,15 @@ def test_service_selection_delivers_dabplus_access_units():
     first = tx.index(rx[0][3])                               # first AU delivered after the interleaver filled
     assert first % 3 == 0                                    # starts on a super frame boundary (3 AUs per super frame)
     assert [g[3] for g in rx] == tx[first:first + len(rx)]
+    # dynamic label segments (dabsdrDynamicLabelCBFunc_t, dabsdr.h:81-86): prefix + characters, assembled as dldecoder.cpp does
+    with lock:
+        segs = list(labels)
+    assert len(segs) >= 4
+    start = next(i for i, sg in enumerate(segs) if sg[0] & 0x40)                    # a "first" segment
+    msg, i = b"", start
+    while True:
+        msg += segs[i][2:2 + (segs[i][0] & 0x0F) + 1]
+        if segs[i][0] & 0x20:
+            break
+        i += 1
+    assert msg.decode("latin-1") == dl_text
