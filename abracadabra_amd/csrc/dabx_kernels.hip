@@ -573,12 +573,14 @@ struct VitSrc {
 // index): logical frame r takes exactly one residue class from each of 16 rows, so this
 // layout makes every (row, residue) read contiguous instead of one byte per 16.
 
-__device__ __forceinline__ int8_t soft_at(const VitSrc &src, uint32_t i)
+// byte offset (from src.base) of coded bit i of the codeword
+__device__ __forceinline__ uint32_t soft_off(const VitSrc &src, uint32_t i)
 {
-    if (src.slot_mask < 0) return src.base[i];
+    if (src.slot_mask < 0) return i;
     uint32_t d = __builtin_bitreverse32(i) >> 28;              // delay of bit i: bit-reversed (i mod 16)
-    // sub-channels start on 64-bit boundaries, so base already points at (start_bit >> 4)
-    return src.base[(size_t)((src.r + d) & src.slot_mask) * CIFBITS + (i & 15u) * TI_SEG + (i >> 4)];
+    // sub-channels start on 64-bit boundaries, so base already points at (start_bit >> 4).  The offset
+    // stays below 2^32 (at most 64 rows of 55296 bytes): 24-bit multiplies, scalar base + vector offset
+    return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(i & 15u, (uint32_t)TI_SEG) + (i >> 4);
 }
 
 // depuncturing word of trellis step tau (0 = past the end: nothing to fetch)
@@ -590,11 +592,11 @@ __device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info,
 __device__ __forceinline__ int gather_step(const VitSrc &src, uint32_t w)
 {
     uint32_t off = w >> 4;
-    int x = 0;
+    int b[4] = {0, 0, 0, 0};                       // the (up to) four loads are issued before any result is used
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (w & (8u >> j)) { x |= ((int)soft_at(src, off) & 0xff) << (8 * j); ++off; }
-    return x;
+        if (w & (8u >> j)) { b[j] = (int)reinterpret_cast<const uint8_t *>(src.base)[soft_off(src, off)]; ++off; }
+    return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
 }
 
 // ---- one add-compare-select step, hand scheduled (6 VALU issues):
