@@ -93,13 +93,27 @@ __device__ __forceinline__ void load_twiddles(Twiddles &tw, const float2 *__rest
     }
 }
 
+// Twiddles of passes B and C for all threads of a workgroup: B depends on t & 31, C on t & 3.  k_demod keeps
+// them in LDS (252 values) instead of 28 VGPRs per thread: that is what lets four of its waves share a SIMD.
+constexpr int TWL = 7 * 32 + 7 * 4;
+__device__ __forceinline__ void load_twiddles_lds(cf a[7], float2 *twl, const float2 *__restrict__ W, int t)
+{
+#pragma unroll
+    for (int c = 1; c < 8; ++c) { float2 x = W[t * c]; a[c - 1] = {x.x, x.y}; }
+    if (t < 7 * 32) { const int b = t / 7, c = t % 7 + 1; twl[t] = W[8 * b * c]; }
+    if (t < 7 * 4) { const int e = t / 7, c = t % 7 + 1; twl[7 * 32 + t] = W[64 * e * c]; }
+    __syncthreads();
+}
+
 // in: v[j] = x[t + 256 j]; out: v[e] = X[bin_of_pos(8 t + e)].  buf: FFT_LDS float2.
 // The caller must __syncthreads() before the next use of buf.
-__device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twiddles &tw)
+// twa/twb/twc: the thread's twiddles of the three radix-8 passes (registers), or, when twl is given,
+// passes B and C read theirs from the LDS table of load_twiddles_lds().
+__device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const cf *twa, const cf *twb, const cf *twc, const float2 *twl)
 {
     r8(v);
 #pragma unroll
-    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw.a[c - 1]);
+    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], twa[c - 1]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(t + 256 * c)] = make_float2(v[c].r, v[c].i);
     __syncthreads();
@@ -108,7 +122,10 @@ __device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twidd
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 32 * j)]; v[j] = {x.x, x.y}; }
     r8(v);
 #pragma unroll
-    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw.b[c - 1]);
+    for (int c = 1; c < 8; ++c) {
+        if (twl) { float2 w = twl[(t & 31) * 7 + c - 1]; v[c] = cmul(v[c], {w.x, w.y}); }
+        else v[c] = cmul(v[c], twb[c - 1]);
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 32 * c)] = make_float2(v[c].r, v[c].i);
     __syncthreads();
@@ -117,7 +134,10 @@ __device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twidd
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 4 * j)]; v[j] = {x.x, x.y}; }
     r8(v);
 #pragma unroll
-    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], tw.c[c - 1]);
+    for (int c = 1; c < 8; ++c) {
+        if (twl) { float2 w = twl[7 * 32 + (t & 3) * 7 + c - 1]; v[c] = cmul(v[c], {w.x, w.y}); }
+        else v[c] = cmul(v[c], twc[c - 1]);
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].r, v[c].i);
     __syncthreads();
@@ -125,6 +145,10 @@ __device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twidd
     for (int e = 0; e < 8; ++e) { float2 x = buf[pad(8 * t + e)]; v[e] = {x.x, x.y}; }
     r4(v[0], v[1], v[2], v[3]);
     r4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twiddles &tw)
+{
+    fft2048_core(v, buf, t, tw.a, tw.b, tw.c, nullptr);
 }
 
 // fixed-order block sum (256 threads): xor butterfly in each wave, then (W0+W1)+(W2+W3)
@@ -449,7 +473,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
 constexpr int DEMOD_GROUPS = 4, DEMOD_GSYMS = 19;
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k_demod(DevCtx C, int n_frames)
+__global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 {
     const int g = blockIdx.x % DEMOD_GROUPS;
     const int sf = blockIdx.x / DEMOD_GROUPS;
@@ -466,11 +490,12 @@ __global__ __launch_bounds__(256) void k_demod(DevCtx C, int n_frames)
     int8_t *ti = C.ti + (size_t)s * C.ti_slots * CIFBITS;
     const int64_t cif0 = st.cif + 4 * (int64_t)f;
 
-    Twiddles tw;
-    load_twiddles(tw, T.W, t);
-    int nidx[8];
+    __shared__ float2 twl[TWL];
+    cf twa[7];
+    load_twiddles_lds(twa, twl, T.W, t);
+    __shared__ int16_t nidx_l[TU];                       // frequency de-interleaver target of each FFT output position (-1: unused bin)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) nidx[e] = T.n_of_bin[T.bin_of_pos[8 * t + e]];
+    for (int e = 0; e < 8; ++e) nidx_l[8 * t + e] = T.n_of_bin[T.bin_of_pos[8 * t + e]];
 
     const int l_first = g * DEMOD_GSYMS;                 // first symbol to demap (0 = PRS: reference only)
     const int l_ref = l_first == 0 ? 0 : l_first - 1;    // symbol whose spectrum seeds the differential
@@ -481,10 +506,13 @@ __global__ __launch_bounds__(256) void k_demod(DevCtx C, int n_frames)
         load_window<FMT>(v, T, ring, C.ring_len, widx, (uint32_t)(l * TS), rec.inc, t);
         widx += TS;
         if (widx >= C.ring_len) widx -= C.ring_len;
-        fft2048(v, buf, t, tw);
+        fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
         if (l > l_ref) {
             cf y[8];
+            int nidx[8];
             float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nidx[e] = nidx_l[8 * t + e];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 y[e] = cmulc(v[e], prev[e]);
