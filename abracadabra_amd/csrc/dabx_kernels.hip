@@ -141,8 +141,11 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].r, v[c].i);
     __syncthreads();
+    {   // positions 8t .. 8t+7 are contiguous (never across a pad): four 16-byte reads, conflict-free per 8 lanes
+        const float4 *p = reinterpret_cast<const float4 *>(buf + pad(8 * t));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { float2 x = buf[pad(8 * t + e)]; v[e] = {x.x, x.y}; }
+        for (int e = 0; e < 4; ++e) { float4 x = p[e]; v[2 * e] = {x.x, x.y}; v[2 * e + 1] = {x.z, x.w}; }
+    }
     r4(v[0], v[1], v[2], v[3]);
     r4(v[4], v[5], v[6], v[7]);
 }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         if (t == 0) { DevSync z = {}; rec = z; }
         return;
     }
-    __shared__ float2 buf[FFT_LDS];
+    __shared__ __attribute__((aligned(16))) float2 buf[FFT_LDS];
     __shared__ float2 nat[TU];
     __shared__ float red[4];
     __shared__ int64_t red64[16];
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     if (st.acq_fail) return;
     const DevSync rec = C.sync[(size_t)s * C.max_frames + f];
     const DevTables &T = C.tab;
-    __shared__ float2 buf[FFT_LDS];
+    __shared__ __attribute__((aligned(16))) float2 buf[FFT_LDS];
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) int8_t soft[SYMBITS];
     const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
 // stage-level FFT: one workgroup per vector, natural order in and out
 __global__ __launch_bounds__(256) void k_fft(DevTables T, const float2 *in, float2 *out)
 {
-    __shared__ float2 buf[FFT_LDS];
+    __shared__ __attribute__((aligned(16))) float2 buf[FFT_LDS];
     const int t = threadIdx.x;
     Twiddles tw;
     load_twiddles(tw, T.W, t);
