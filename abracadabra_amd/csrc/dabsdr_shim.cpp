@@ -71,7 +71,7 @@ struct dabsdr_s {
     int sel_ascty = 0, sel_kbps = 0;
     dabsdrDecoderId_t sel_id = DABSDR_ID_AUDIO_PRIMARY;
     uint32_t sf_stats[6] = {0}, last_sf_stats[6] = {0};   // k_superframe totals: super frames, AUs good/bad, RS corrected/uncorrectable, sync losses
-    std::vector<uint8_t> sf_data;
+    std::vector<uint8_t> sf_data, mp2_half;
     pad::Decoder pad;                     // X-PAD of the selected DAB+ service -> dynamic label / data group callbacks
     uint32_t audio_bytes_acc = 0;
     std::vector<figdb::UserApp> app_snapshot, sel_apps;
@@ -301,6 +301,7 @@ void handle_request(dabsdr_s *h, const Request &r)
                     h->sel_id = static_cast<dabsdrDecoderId_t>(r.c);
                     if (h->sel_ascty == 63 && dabx_set_dabplus(h->ctx, 0, 1) != DABX_OK) h->sel_ascty = -1;   // DAB+: super frames on the GPU
                     h->pad.reset();
+                    h->mp2_half.clear();
                     h->sel_apps = c.apps;
                     std::memset(h->sf_stats, 0, sizeof h->sf_stats);
                     std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
@@ -363,6 +364,22 @@ void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
         float v = std::nearbyint(in[i] * g);
         out[i] = static_cast<int16_t>(v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v));
     }
+}
+
+// MPEG Layer II audio frames: 48 kHz frames are one logical frame long, 24 kHz (LSF) frames two; the second half
+// of an LSF frame does not start with a sync word
+void feed_mp2_pad(dabsdr_s *h, const uint8_t *frame, int len)
+{
+    const bool sync = len >= 4 && frame[0] == 0xFF && (frame[1] & 0xF0) == 0xF0;
+    if (!h->mp2_half.empty()) {                                       // second logical frame of an LSF audio frame
+        h->mp2_half.insert(h->mp2_half.end(), frame, frame + len);
+        h->pad.feed_mp2_frame(h->mp2_half.data(), static_cast<int>(h->mp2_half.size()));
+        h->mp2_half.clear();
+        return;
+    }
+    if (!sync) return;
+    if (!((frame[1] >> 3) & 1)) h->mp2_half.assign(frame, frame + len);   // LSF: wait for the other half
+    else h->pad.feed_mp2_frame(frame, len);
 }
 
 void after_step(dabsdr_s *h)
@@ -474,6 +491,7 @@ void after_step(dabsdr_s *h)
                     d.auLen = static_cast<uint16_t>(3 * h->sel_kbps); d.pAuData = msc.data() + static_cast<size_t>(c) * 3 * h->sel_kbps;
                     h->audio_bytes_acc += d.auLen;
                     h->audio_cb(&d, h->audio_ctx);
+                    if (h->sel_ascty == 0) feed_mp2_pad(h, d.pAuData, d.auLen);   // MPEG Layer II: PAD at the end of the audio frame
                 }
         }
     }
@@ -669,6 +687,28 @@ DABSDR_API int dabsdr_amd_pad_decode(const uint8_t *aus, int n_bytes, uint8_t *o
         const int len = aus[pos] | (aus[pos + 1] << 8);
         if (pos + 2 + len > n_bytes) break;
         dec.feed_dabplus_au(aus + pos + 2, len);
+        pos += 2 + len;
+    }
+    if (stats) { stats[0] = dec.stats.pads; stats[1] = dec.stats.dl_ok; stats[2] = dec.stats.dl_crc_err; stats[3] = dec.stats.dg_ok; stats[4] = dec.stats.dg_crc_err; }
+    return overflow ? -1 : used;
+}
+
+// test hook (CPU only): the same for MPEG Layer II audio frames (records: len lo, len hi, frame bytes)
+DABSDR_API int dabsdr_amd_pad_decode_mp2(const uint8_t *frames, int n_bytes, uint8_t *out, int cap, uint32_t *stats)
+{
+    pad::Decoder dec;
+    int used = 0;
+    bool overflow = false;
+    dec.on_dynamic_label = [&](const uint8_t *d, int n) {
+        if (used + 4 + n > cap) { overflow = true; return; }
+        out[used] = 'L'; out[used + 1] = 2; out[used + 2] = static_cast<uint8_t>(n & 0xFF); out[used + 3] = static_cast<uint8_t>(n >> 8);
+        std::memcpy(out + used + 4, d, static_cast<size_t>(n));
+        used += 4 + n;
+    };
+    for (int pos = 0; pos + 2 <= n_bytes;) {
+        const int len = frames[pos] | (frames[pos + 1] << 8);
+        if (pos + 2 + len > n_bytes) break;
+        dec.feed_mp2_frame(frames + pos + 2, len);
         pos += 2 + len;
     }
     if (stats) { stats[0] = dec.stats.pads; stats[1] = dec.stats.dl_ok; stats[2] = dec.stats.dl_crc_err; stats[3] = dec.stats.dg_ok; stats[4] = dec.stats.dg_crc_err; }

@@ -48,8 +48,31 @@ public:
         feed_pad(au + pos, count);
     }
 
+    // One MPEG-1/2 Layer II frame of a DAB audio sub-channel (EN 300 401 §7.3.2.4, §B): the frame ends with
+    // X-PAD | ScF-CRC (2 bytes below 56 kbit/s per channel, else 4) | F-PAD (2 bytes).  24 kHz (LSF) frames span two
+    // logical frames; the caller passes whole audio frames.
+    void feed_mp2_frame(const uint8_t *f, int len)
+    {
+        if (len < 8 || f[0] != 0xFF || (f[1] & 0xF0) != 0xF0) return;       // 12-bit sync word
+        const bool lsf = !((f[1] >> 3) & 1);                                 // ID bit: 1 = 48 kHz (MPEG-1), 0 = 24 kHz (MPEG-2 LSF)
+        static const int kBr1[16] = {0, 32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 0};
+        static const int kBr2[16] = {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 0};
+        const int kbps = (lsf ? kBr2 : kBr1)[f[2] >> 4];
+        const bool mono = (f[3] >> 6) == 3;
+        if (!kbps) return;
+        const int scf = (kbps / (mono ? 1 : 2) >= 56) ? 4 : 2;
+        const int room = len - 2 - scf - 4;                                  // bytes that can hold X-PAD (after the 4-byte header)
+        if (room <= 0) return;
+        const int nx = room < 196 ? room : 196;                              // 4 CIs + 4 x 48 bytes is the largest X-PAD
+        uint8_t tmp[196 + 2];
+        for (int i = 0; i < nx; ++i) tmp[i] = f[len - 2 - scf - nx + i];
+        tmp[nx] = f[len - 2]; tmp[nx + 1] = f[len - 1];
+        feed_pad(tmp, nx + 2, false);
+    }
+
     // pad: the whole PAD field, its last two bytes are the F-PAD; the X-PAD before them is read backwards
-    void feed_pad(const uint8_t *pad, int n)
+    // exact: n is the true PAD length (DAB+); otherwise the X-PAD may be shorter than n - 2 (MPEG Layer II frames)
+    void feed_pad(const uint8_t *pad, int n, bool exact = true)
     {
         if (n < 2) return;
         ++stats.pads;
@@ -68,7 +91,7 @@ public:
             return;
         }
         if (!ci_flag) {                                       // variable size without indicators: continuation of the last application
-            if (last_app_ >= 0) subfield(last_app_, x.data(), xlen, false);
+            if (last_app_ >= 0 && exact) subfield(last_app_, x.data(), xlen, false);
             return;
         }
         int apps[4], lens[4], nci = 0, p = 0;

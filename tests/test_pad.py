@@ -138,3 +138,44 @@ def test_garbage_does_not_crash():
     aus = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(1, 400, 300)]
     aus += [bytes([0x80, 250]) + bytes(5), bytes([0x80, 255]), bytes([0x80, 255, 10]) + bytes(40)]
     decode(aus)
+
+
+# ---- MPEG Layer II (DAB audio): the PAD sits at the end of the audio frame, before and after the ScF-CRC
+
+def mp2_frame(kbps, pad, mono=False, lsf=False):
+    """a syntactically plausible Layer II frame of 3*kbps (48 kHz) or 6*kbps (24 kHz) bytes ending in X-PAD | ScF-CRC | F-PAD"""
+    br = {False: [0, 32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384], True: [0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160]}[lsf]
+    hdr = bytes([0xFF, 0xF0 | ((0 if lsf else 1) << 3) | (2 << 1) | 1, (br.index(kbps) << 4) | (1 << 2), (3 if mono else 0) << 6])
+    n = (6 if lsf else 3) * kbps
+    scf = 4 if kbps // (1 if mono else 2) >= 56 else 2
+    rng = np.random.default_rng(kbps)
+    body = bytes(rng.integers(0, 256, n - 4 - len(pad) - scf, dtype=np.uint8))
+    xpad, fpad = pad[:-2], pad[-2:]
+    return hdr + body + xpad + bytes(scf) + fpad
+
+
+def decode_mp2(frames):
+    L = aa.load_library()
+    L.dabsdr_amd_pad_decode_mp2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    blob = np.frombuffer(b"".join(bytes([len(a) & 0xFF, len(a) >> 8]) + a for a in frames), dtype=np.uint8).copy()
+    out = np.zeros(1 << 16, dtype=np.uint8)
+    stats = np.zeros(5, dtype=np.uint32)
+    n = L.dabsdr_amd_pad_decode_mp2(blob.ctypes.data, blob.size, out.ctypes.data, out.size, stats.ctypes.data)
+    assert n >= 0
+    recs, pos = [], 0
+    while pos < n:
+        ln = int(out[pos + 2]) | (int(out[pos + 3]) << 8)
+        recs.append(bytes(out[pos + 4:pos + 4 + ln]))
+        pos += 4 + ln
+    return recs, stats.tolist()
+
+
+def test_dynamic_label_from_mpeg_layer2_frames():
+    text = "DAB classic: Layer II with a dynamic label"
+    for kbps, mono, lsf in ((128, False, False), (64, True, False), (48, False, True), (192, False, False)):
+        groups = dl_groups(text, toggle=0)
+        frames = [mp2_frame(kbps, xpad_var([sub]), mono, lsf) for g in groups for sub in spread(g, 2, 12)]
+        frames.insert(2, mp2_frame(kbps, bytes([0x00, 0x00]), mono, lsf))     # no X-PAD in this frame
+        recs, st = decode_mp2(frames)
+        assert recs == [g[:-2] for g in groups], (kbps, mono, lsf)
+        assert b"".join(r[2:] for r in recs).decode("latin-1") == text
