@@ -11,6 +11,7 @@
 #include "../../include/dabsdr_amd.h"
 #include "../../include/dabx.h"
 #include "fig_db.hpp"
+#include "packet.hpp"
 #include "pad.hpp"
 #include "tii.hpp"
 
@@ -22,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -41,6 +43,25 @@ struct Request {
 constexpr int kPullChunk = 16384;        // complex samples per input-callback call (uint16_t length)
 
 }  // namespace
+
+// one selected service component (dabsdrRequest_ServiceSelection): what it needs from the GPU context and its
+// host-side decoders.  The reference runs a primary audio, a secondary audio and data decoders side by side
+// (dabsdrDecoderId_t, dabsdr.h:22-28).
+struct Selection {
+    uint32_t sid = 0;
+    int scids = -1;
+    dabsdrDecoderId_t id = DABSDR_ID_AUDIO_PRIMARY;
+    bool packet = false;                  // TMId 3: packet mode data
+    int ascty = 0;                        // audio: 63 = DAB+, 0 = MPEG Layer II; packet: DSCTy
+    int kbps = 0, scid = 0;
+    dabx_subch_t sub = {};                // the sub-channel to decode
+    int subch_id = -1;
+    std::vector<figdb::UserApp> apps;     // FIG 0/13: maps X-PAD application types to user application types
+    pad::Decoder pad;                     // X-PAD -> dynamic label / data groups
+    packet::Decoder pkt;                  // packet mode -> data groups
+    std::vector<uint8_t> mp2_half;        // first half of a 24 kHz Layer II frame
+    uint32_t sf_stats[6] = {0};           // k_superframe totals of this sub-channel
+};
 
 struct dabsdr_s {
     dabx_ctx *ctx = nullptr;
@@ -67,14 +88,11 @@ struct dabsdr_s {
     int period_frames = 0;
     uint32_t fib_err_acc = 0;
     figdb::Database db;
-    uint32_t sel_sid = 0; int sel_scids = -1; bool sel_active = false;
-    int sel_ascty = 0, sel_kbps = 0;
-    dabsdrDecoderId_t sel_id = DABSDR_ID_AUDIO_PRIMARY;
-    uint32_t sf_stats[6] = {0}, last_sf_stats[6] = {0};   // k_superframe totals: super frames, AUs good/bad, RS corrected/uncorrectable, sync losses
-    std::vector<uint8_t> sf_data, mp2_half;
-    pad::Decoder pad;                     // X-PAD of the selected DAB+ service -> dynamic label / data group callbacks
+    std::vector<std::unique_ptr<Selection>> sel;   // running decoders: primary / secondary audio, data components
+    uint32_t last_sf_stats[6] = {0};      // primary audio's k_superframe totals at the last periodic notification
+    std::vector<uint8_t> sf_data;
     uint32_t audio_bytes_acc = 0;
-    std::vector<figdb::UserApp> app_snapshot, sel_apps;
+    std::vector<figdb::UserApp> app_snapshot;
     bool spectrum_on = false, tii_on = false;
     int tii_mode = DABSDR_TII_MODE_DEFAULT;
     std::vector<float> spectrum, null_power;
@@ -183,8 +201,46 @@ void reset_receiver(dabsdr_s *h, dabsdrNtfResetFlags_t flag)
     h->db.clear();
     h->sync_level = DABSDR_SYNC_LEVEL_NO_SYNC;
     h->fib_err_acc = 0; h->period_frames = 0;
-    h->sel_active = false;
+    h->sel.clear();
     notify(h, DABSDR_NID_RESET, DABSDR_NSTAT_SUCCESS, &flag, 0);
+}
+
+// (re)program the GPU context with the sub-channels of all running selections, in the order of h->sel
+bool apply_selections(dabsdr_s *h)
+{
+    if (!h->ctx) return false;
+    std::vector<dabx_subch_t> subs;
+    uint64_t dabplus = 0;
+    for (size_t k = 0; k < h->sel.size(); ++k) {
+        subs.push_back(h->sel[k]->sub);
+        if (!h->sel[k]->packet && h->sel[k]->ascty == 63) dabplus |= 1ull << k;
+    }
+    if (dabx_set_subchannels(h->ctx, 0, static_cast<int>(subs.size()), subs.empty() ? nullptr : subs.data()) < 0) return false;
+    if (dabplus && dabx_set_dabplus(h->ctx, 0, dabplus) != DABX_OK) return false;
+    return true;                                           // running decoders (and their super frame state on the GPU) carry on
+}
+
+void wire_callbacks(dabsdr_s *h, Selection *sp)
+{
+    sp->pad.on_dynamic_label = [h, sp](const uint8_t *d, int n) {
+        if (!h->dl_cb) return;
+        dabsdrDynamicLabelCBData_t cb = {sp->id, static_cast<uint16_t>(n), d};
+        h->dl_cb(&cb, h->dl_ctx);
+    };
+    sp->pad.on_data_group = [h, sp](int xpad_app, const uint8_t *d, int n) {
+        if (!h->dg_cb) return;
+        uint16_t type = xpad_app == 12 ? 0x002 : 0;                   // default: MOT slide show; else what FIG 0/13 announces
+        for (const auto &a : sp->apps)
+            if (!a.data.empty() && (a.data[0] & 0x1F) == xpad_app) type = static_cast<uint16_t>(a.type);
+        dabsdrDataGroupCBData_t cb = {sp->id, 0, type, static_cast<uint16_t>(n), d};
+        h->dg_cb(&cb, h->dg_ctx);
+    };
+    sp->pkt.on_data_group = [h, sp](int, const uint8_t *d, int n) {
+        if (!h->dg_cb) return;
+        const uint16_t type = sp->apps.empty() ? 0 : static_cast<uint16_t>(sp->apps[0].type);
+        dabsdrDataGroupCBData_t cb = {sp->id, static_cast<uint16_t>(sp->scid), type, static_cast<uint16_t>(n), d};
+        h->dg_cb(&cb, h->dg_ctx);
+    };
 }
 
 void handle_request(dabsdr_s *h, const Request &r)
@@ -289,23 +345,40 @@ void handle_request(dabsdr_s *h, const Request &r)
         const figdb::Service *sv = h->db.find_service(r.a);
         if (sv && h->ctx) {
             for (const auto &c : sv->comp) {
-                if (c.scids != r.b) continue;
-                auto it = h->db.subch.find(c.subch);
-                if (c.tmid == 3 || it == h->db.subch.end()) { st = DABSDR_NSTAT_SERVICE_NOT_READY; break; }
-                dabx_subch_t sc = {it->second.start, it->second.option, it->second.level, it->second.kbps};
-                if (!it->second.long_form) sc = {it->second.start, 2, it->second.uep_index, 0};   // UEP short form
-                st = dabx_set_subchannels(h->ctx, 0, 1, &sc) >= 0 ? DABSDR_NSTAT_SUCCESS : DABSDR_NSTAT_SERVICE_NOT_SUPPORTED;
-                if (st == DABSDR_NSTAT_SUCCESS) {
-                    h->sel_sid = r.a; h->sel_scids = r.b; h->sel_active = true;
-                    h->sel_ascty = c.ascty_dscty; h->sel_kbps = it->second.kbps;
-                    h->sel_id = static_cast<dabsdrDecoderId_t>(r.c);
-                    if (h->sel_ascty == 63 && dabx_set_dabplus(h->ctx, 0, 1) != DABX_OK) h->sel_ascty = -1;   // DAB+: super frames on the GPU
-                    h->pad.reset();
-                    h->mp2_half.clear();
-                    h->sel_apps = c.apps;
-                    std::memset(h->sf_stats, 0, sizeof h->sf_stats);
-                    std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
+                if (c.scids != static_cast<int>(r.b)) continue;
+                int subch = c.subch;
+                const figdb::PacketComponent *pk = nullptr;
+                if (c.tmid == 3) {                        // packet mode: FIG 0/3 names the sub-channel and the packet address
+                    auto pi = h->db.packet.find(c.scid);
+                    if (pi == h->db.packet.end()) { st = DABSDR_NSTAT_SERVICE_NOT_READY; break; }
+                    pk = &pi->second;
+                    subch = pk->subch;
                 }
+                auto it = h->db.subch.find(subch);
+                if (it == h->db.subch.end()) { st = DABSDR_NSTAT_SERVICE_NOT_READY; break; }
+                auto sp = std::make_unique<Selection>();
+                sp->sid = r.a; sp->scids = static_cast<int>(r.b); sp->id = static_cast<dabsdrDecoderId_t>(r.c);
+                sp->packet = pk != nullptr;
+                sp->ascty = pk ? pk->dscty : c.ascty_dscty;
+                sp->kbps = it->second.kbps;
+                sp->scid = c.scid;
+                sp->subch_id = subch;
+                sp->apps = c.apps;
+                sp->sub = {it->second.start, it->second.option, it->second.level, it->second.kbps};
+                if (!it->second.long_form) sp->sub = {it->second.start, 2, it->second.uep_index, 0};   // UEP short form
+                if (pk) sp->pkt.address = pk->packet_address;
+                // an audio decoder id holds one component; a data component replaces an earlier selection of itself
+                std::vector<std::unique_ptr<Selection>> keep;
+                for (auto &o : h->sel) {
+                    const bool same = sp->id == DABSDR_ID_DATA ? (o->id == DABSDR_ID_DATA && o->sid == sp->sid && o->scids == sp->scids) : o->id == sp->id;
+                    if (!same) keep.push_back(std::move(o));
+                }
+                h->sel = std::move(keep);
+                wire_callbacks(h, sp.get());
+                if (sp->id == DABSDR_ID_AUDIO_PRIMARY) std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
+                h->sel.push_back(std::move(sp));
+                if (apply_selections(h)) st = DABSDR_NSTAT_SUCCESS;
+                else { h->sel.pop_back(); apply_selections(h); st = DABSDR_NSTAT_SERVICE_NOT_SUPPORTED; }
                 break;
             }
         }
@@ -314,8 +387,14 @@ void handle_request(dabsdr_s *h, const Request &r)
     }
     case Req::ServiceStop: {
         dabsdrNtfServiceStop_t s = {r.a, static_cast<uint8_t>(r.b), static_cast<dabsdrDecoderId_t>(r.c)};
-        if (h->ctx) dabx_set_subchannels(h->ctx, 0, 0, nullptr);
-        h->sel_active = false;
+        std::vector<std::unique_ptr<Selection>> keep;
+        for (auto &o : h->sel) {
+            const bool hit = static_cast<dabsdrDecoderId_t>(r.c) == DABSDR_ID_DATA ? (o->id == DABSDR_ID_DATA && o->sid == r.a && o->scids == static_cast<int>(r.b))
+                                                                                  : o->id == static_cast<dabsdrDecoderId_t>(r.c);
+            if (!hit) keep.push_back(std::move(o));
+        }
+        h->sel = std::move(keep);
+        apply_selections(h);
         notify(h, DABSDR_NID_SERVICE_STOP, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
         break;
     }
@@ -368,18 +447,18 @@ void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
 
 // MPEG Layer II audio frames: 48 kHz frames are one logical frame long, 24 kHz (LSF) frames two; the second half
 // of an LSF frame does not start with a sync word
-void feed_mp2_pad(dabsdr_s *h, const uint8_t *frame, int len)
+void feed_mp2_pad(Selection *sp, const uint8_t *frame, int len)
 {
     const bool sync = len >= 4 && frame[0] == 0xFF && (frame[1] & 0xF0) == 0xF0;
-    if (!h->mp2_half.empty()) {                                       // second logical frame of an LSF audio frame
-        h->mp2_half.insert(h->mp2_half.end(), frame, frame + len);
-        h->pad.feed_mp2_frame(h->mp2_half.data(), static_cast<int>(h->mp2_half.size()));
-        h->mp2_half.clear();
+    if (!sp->mp2_half.empty()) {                                      // second logical frame of an LSF audio frame
+        sp->mp2_half.insert(sp->mp2_half.end(), frame, frame + len);
+        sp->pad.feed_mp2_frame(sp->mp2_half.data(), static_cast<int>(sp->mp2_half.size()));
+        sp->mp2_half.clear();
         return;
     }
     if (!sync) return;
-    if (!((frame[1] >> 3) & 1)) h->mp2_half.assign(frame, frame + len);   // LSF: wait for the other half
-    else h->pad.feed_mp2_frame(frame, len);
+    if (!((frame[1] >> 3) & 1)) sp->mp2_half.assign(frame, frame + len);  // LSF: wait for the other half
+    else sp->pad.feed_mp2_frame(frame, len);
 }
 
 void after_step(dabsdr_s *h)
@@ -456,43 +535,54 @@ void after_step(dabsdr_s *h)
             }
         }
     }
-    // selected audio service -> audio callback (dabsdr.h:47-78): DAB+ access units come from k_superframe's records
+    // running selections.  Audio (dabsdrAudioCBFunc_t, dabsdr.h:47-78): DAB+ access units come from k_superframe's records
     // (a damaged unit keeps its place with the conceal bit set, as audiodecoder.cpp:183-208 expects), MPEG Layer II
-    // sub-channels are handed over one logical frame at a time
-    if (h->sel_active && h->audio_cb && h->sel_kbps > 0) {
-        if (h->sel_ascty == 63) {
-            const int s8 = h->sel_kbps / 8;
-            dabx_superframe_t recs[2];
-            h->sf_data.resize(2 * 110 * static_cast<size_t>(s8));
-            const int n = dabx_get_superframes(h->ctx, 0, 0, recs, h->sf_data.data(), 2);
-            for (int k = 0; k < n; ++k) {
-                const uint8_t *base = h->sf_data.data() + static_cast<size_t>(k) * 110 * s8;
-                for (int a = 0; a < recs[k].num_aus; ++a) {
-                    if (!((recs[k].au_valid >> a) & 1)) continue;
-                    dabsdrAudioCBData_t d;
-                    d.id = h->sel_id; d.ASCTy = 63;
-                    d.header.raw = static_cast<uint8_t>(recs[k].header | (((recs[k].au_ok >> a) & 1) ? 0 : 0x80));
-                    d.auLen = static_cast<uint16_t>(recs[k].au_start[a + 1] - recs[k].au_start[a] - 2);
-                    d.pAuData = base + recs[k].au_start[a];
-                    h->audio_bytes_acc += d.auLen;
-                    h->audio_cb(&d, h->audio_ctx);
-                    if ((recs[k].au_ok >> a) & 1) h->pad.feed_dabplus_au(d.pAuData, d.auLen);
+    // sub-channels are handed over one logical frame at a time; their PAD feeds the dynamic label / data group
+    // callbacks.  Packet-mode data components: packets -> MSC data groups -> dabsdrDataGroupCBFunc_t.
+    if (!h->sel.empty()) {
+        size_t stride = 0;
+        for (const auto &sp : h->sel) stride += static_cast<size_t>(3 * sp->kbps);
+        std::vector<uint8_t> msc(4 * stride);
+        uint8_t valid[4] = {0, 0, 0, 0};
+        const bool have_msc = dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK;
+        size_t off = 0;
+        for (size_t k = 0; k < h->sel.size(); ++k) {
+            Selection *sp = h->sel[k].get();
+            const size_t fb = static_cast<size_t>(3 * sp->kbps);
+            if (!sp->packet && sp->ascty == 63) {
+                const int s8 = sp->kbps / 8;
+                dabx_superframe_t recs[2];
+                h->sf_data.resize(2 * 110 * static_cast<size_t>(s8));
+                const int n = dabx_get_superframes(h->ctx, 0, static_cast<int>(k), recs, h->sf_data.data(), 2);
+                for (int q = 0; q < n; ++q) {
+                    const uint8_t *base = h->sf_data.data() + static_cast<size_t>(q) * 110 * s8;
+                    for (int a = 0; a < recs[q].num_aus; ++a) {
+                        if (!((recs[q].au_valid >> a) & 1)) continue;
+                        dabsdrAudioCBData_t d;
+                        d.id = sp->id; d.ASCTy = 63;
+                        d.header.raw = static_cast<uint8_t>(recs[q].header | (((recs[q].au_ok >> a) & 1) ? 0 : 0x80));
+                        d.auLen = static_cast<uint16_t>(recs[q].au_start[a + 1] - recs[q].au_start[a] - 2);
+                        d.pAuData = base + recs[q].au_start[a];
+                        if (sp->id == DABSDR_ID_AUDIO_PRIMARY) h->audio_bytes_acc += d.auLen;
+                        if (h->audio_cb) h->audio_cb(&d, h->audio_ctx);
+                        if ((recs[q].au_ok >> a) & 1) sp->pad.feed_dabplus_au(d.pAuData, d.auLen);
+                    }
                 }
-            }
-            if (n >= 0) dabx_get_superframe_stats(h->ctx, 0, 0, h->sf_stats);
-        } else if (h->sel_ascty >= 0) {
-            std::vector<uint8_t> msc(4 * static_cast<size_t>(3 * h->sel_kbps));
-            uint8_t valid[4];
-            if (dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK)
+                if (n >= 0) dabx_get_superframe_stats(h->ctx, 0, static_cast<int>(k), sp->sf_stats);
+            } else if (have_msc) {
                 for (int c = 0; c < 4; ++c) {
                     if (!valid[c]) continue;
+                    const uint8_t *frame = msc.data() + static_cast<size_t>(c) * stride + off;
+                    if (sp->packet) { sp->pkt.feed_frame(frame, static_cast<int>(fb)); continue; }
                     dabsdrAudioCBData_t d;
-                    d.id = h->sel_id; d.ASCTy = static_cast<uint8_t>(h->sel_ascty); d.header.raw = 0;
-                    d.auLen = static_cast<uint16_t>(3 * h->sel_kbps); d.pAuData = msc.data() + static_cast<size_t>(c) * 3 * h->sel_kbps;
-                    h->audio_bytes_acc += d.auLen;
-                    h->audio_cb(&d, h->audio_ctx);
-                    if (h->sel_ascty == 0) feed_mp2_pad(h, d.pAuData, d.auLen);   // MPEG Layer II: PAD at the end of the audio frame
+                    d.id = sp->id; d.ASCTy = static_cast<uint8_t>(sp->ascty); d.header.raw = 0;
+                    d.auLen = static_cast<uint16_t>(fb); d.pAuData = frame;
+                    if (sp->id == DABSDR_ID_AUDIO_PRIMARY) h->audio_bytes_acc += d.auLen;
+                    if (h->audio_cb) h->audio_cb(&d, h->audio_ctx);
+                    if (sp->ascty == 0) feed_mp2_pad(sp, frame, static_cast<int>(fb));   // MPEG Layer II: PAD at the end of the audio frame
                 }
+            }
+            off += fb;
         }
     }
     if (h->period_log2 >= 0 && ++h->period_frames >= (1 << h->period_log2)) {
@@ -507,14 +597,18 @@ void after_step(dabsdr_s *h)
             p.secMsec = static_cast<uint16_t>((h->db.ens.seconds << 10) | h->db.ens.ms);
         }
         p.fibErrorCntr = static_cast<uint16_t>(h->fib_err_acc);
-        const uint32_t *now = h->sf_stats, *was = h->last_sf_stats;
+        static const uint32_t kZero[6] = {0, 0, 0, 0, 0, 0};
+        const uint32_t *now = kZero, *was = h->last_sf_stats;
+        int prim_kbps = 0;
+        for (const auto &sp : h->sel)
+            if (sp->id == DABSDR_ID_AUDIO_PRIMARY) { now = sp->sf_stats; prim_kbps = sp->kbps; }
         p.mscCrcOkCntr = static_cast<uint8_t>(now[1] - was[1]);
         p.mscCrcErrorCntr = static_cast<uint8_t>(now[2] - was[2]);
         p.rsUncorrectableCntr = static_cast<uint16_t>(now[4] - was[4]);
         p.rsBitErrors = static_cast<uint16_t>(now[3] - was[3]);
-        p.rsBytes = static_cast<uint16_t>((now[0] - was[0]) * 120u * static_cast<unsigned>(h->sel_kbps / 8));
+        p.rsBytes = static_cast<uint16_t>((now[0] - was[0]) * 120u * static_cast<unsigned>(prim_kbps / 8));
         p.audioServiceBytes = static_cast<uint16_t>(h->audio_bytes_acc);
-        std::memcpy(h->last_sf_stats, h->sf_stats, sizeof h->sf_stats);
+        std::memcpy(h->last_sf_stats, now, sizeof h->last_sf_stats);
         h->audio_bytes_acc = 0;
         notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, &p, sizeof p);
         h->period_frames = 0; h->fib_err_acc = 0;
@@ -585,19 +679,6 @@ uint8_t dabsdrInit(dabsdrHandle_t *handle)
         return EXIT_FAILURE;
     }
     dabx_enable_spectrum(h->ctx, 2);                 // null-symbol spectrum: noise estimate and TII
-    h->pad.on_dynamic_label = [h](const uint8_t *d, int n) {
-        if (!h->dl_cb) return;
-        dabsdrDynamicLabelCBData_t cb = {h->sel_id, static_cast<uint16_t>(n), d};
-        h->dl_cb(&cb, h->dl_ctx);
-    };
-    h->pad.on_data_group = [h](int xpad_app, const uint8_t *d, int n) {
-        if (!h->dg_cb) return;
-        uint16_t type = xpad_app == 12 ? 0x002 : 0;                   // default: MOT slide show; else what FIG 0/13 announces
-        for (const auto &a : h->sel_apps)
-            if (!a.data.empty() && (a.data[0] & 0x1F) == xpad_app) type = static_cast<uint16_t>(a.type);
-        dabsdrDataGroupCBData_t cb = {h->sel_id, 0, type, static_cast<uint16_t>(n), d};
-        h->dg_cb(&cb, h->dg_ctx);
-    };
     *handle = h;
     return EXIT_SUCCESS;
 }
@@ -712,6 +793,26 @@ DABSDR_API int dabsdr_amd_pad_decode_mp2(const uint8_t *frames, int n_bytes, uin
         pos += 2 + len;
     }
     if (stats) { stats[0] = dec.stats.pads; stats[1] = dec.stats.dl_ok; stats[2] = dec.stats.dl_crc_err; stats[3] = dec.stats.dg_ok; stats[4] = dec.stats.dg_crc_err; }
+    return overflow ? -1 : used;
+}
+
+// test hook (CPU only): logical frames of a packet-mode sub-channel (n_frames x frame_bytes) -> data groups as records
+// {addr lo, addr hi, len lo, len hi, bytes}; address < 0 follows every address; stats[4] = packets, CRC errors, groups, dropped
+DABSDR_API int dabsdr_amd_packet_decode(const uint8_t *frames, int n_frames, int frame_bytes, int address, uint8_t *out, int cap, uint32_t *stats)
+{
+    packet::Decoder dec;
+    dec.address = address;
+    int used = 0;
+    bool overflow = false;
+    dec.on_data_group = [&](int addr, const uint8_t *d, int n) {
+        if (used + 4 + n > cap) { overflow = true; return; }
+        out[used] = static_cast<uint8_t>(addr & 0xFF); out[used + 1] = static_cast<uint8_t>(addr >> 8);
+        out[used + 2] = static_cast<uint8_t>(n & 0xFF); out[used + 3] = static_cast<uint8_t>(n >> 8);
+        std::memcpy(out + used + 4, d, static_cast<size_t>(n));
+        used += 4 + n;
+    };
+    for (int i = 0; i < n_frames; ++i) dec.feed_frame(frames + static_cast<size_t>(i) * frame_bytes, frame_bytes);
+    if (stats) { stats[0] = dec.stats.packets; stats[1] = dec.stats.crc_err; stats[2] = dec.stats.groups; stats[3] = dec.stats.dropped; }
     return overflow ? -1 : used;
 }
 

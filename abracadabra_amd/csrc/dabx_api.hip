@@ -90,6 +90,7 @@ struct dabx_ctx {
     int work_frames = 0, n_work = 0;
     // DAB+ super frame stage (dabx_superframe.hip)
     std::vector<DevSfSub> sf_subs;
+    std::vector<dabx_subch_t> sf_ident;     // what each entry decodes: a sub-channel that stays keeps its synchronisation state
     DevSfSub *d_sf_subs = nullptr; DevSfState *d_sf_state = nullptr; DevSfRec *d_sf_recs = nullptr; uint8_t *d_sf_data = nullptr, *d_gf = nullptr;
     bool sf_dirty = false;
     int sf_max_rec = 0;
@@ -196,10 +197,15 @@ int build_work(dabx_ctx *c, int n_frames)
     return DABX_OK;
 }
 
-// (re)build the list of DAB+ sub-channels; their synchronisation state starts afresh
+// (re)build the list of DAB+ sub-channels.  A sub-channel that was already being decoded (same stream, same
+// position, protection and rate) keeps its state, so that changing the set next to it does not interrupt it.
 int build_superframe_work(dabx_ctx *c)
 {
+    const std::vector<DevSfSub> old_subs = c->sf_subs;
+    const std::vector<dabx_subch_t> old_ident = c->sf_ident;
+    DevSfState *old_state = c->d_sf_state;
     c->sf_subs.clear();
+    c->sf_ident.clear();
     c->sf_max_rec = (4 + 4 * c->cfg.max_frames) / 5;
     uint32_t rec = 0, data = 0;
     for (int s = 0; s < c->cfg.n_streams; ++s) {
@@ -212,13 +218,17 @@ int build_superframe_work(dabx_ctx *c)
             rec += static_cast<uint32_t>(c->sf_max_rec);
             data += static_cast<uint32_t>(c->sf_max_rec) * 110u * static_cast<uint32_t>(kbps / 8);
             c->sf_subs.push_back(d);
+            c->sf_ident.push_back(sh.sub[k]);
         }
     }
-    for (void *p : {static_cast<void *>(c->d_sf_subs), static_cast<void *>(c->d_sf_state), static_cast<void *>(c->d_sf_recs), static_cast<void *>(c->d_sf_data)})
+    for (void *p : {static_cast<void *>(c->d_sf_subs), static_cast<void *>(c->d_sf_recs), static_cast<void *>(c->d_sf_data)})
         if (p) (void)hipFree(p);
     c->d_sf_subs = nullptr; c->d_sf_state = nullptr; c->d_sf_recs = nullptr; c->d_sf_data = nullptr;
     c->sf_dirty = false;
-    if (c->sf_subs.empty()) return DABX_OK;
+    if (c->sf_subs.empty()) {
+        if (old_state) (void)hipFree(old_state);
+        return DABX_OK;
+    }
     if (!c->d_gf) {                                                   // GF(2^8) tables: exp[512], log[256]
         std::vector<uint8_t> tab(768, 0);
         unsigned x = 1;
@@ -232,6 +242,15 @@ int build_superframe_work(dabx_ctx *c)
     if (rc) return rc;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_state), n * sizeof(DevSfState)));
     HIPCHK(hipMemset(c->d_sf_state, 0, n * sizeof(DevSfState)));
+    for (size_t i = 0; i < n && old_state; ++i)
+        for (size_t j = 0; j < old_subs.size(); ++j) {
+            const dabx_subch_t &a = c->sf_ident[i], &b = old_ident[j];
+            if (old_subs[j].stream == c->sf_subs[i].stream && a.start_cu == b.start_cu && a.option == b.option && a.level == b.level && a.kbps == b.kbps) {
+                HIPCHK(hipMemcpy(c->d_sf_state + i, old_state + j, sizeof(DevSfState), hipMemcpyDeviceToDevice));
+                break;
+            }
+        }
+    if (old_state) (void)hipFree(old_state);
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_recs), static_cast<size_t>(rec) * sizeof(DevSfRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_data), std::max<size_t>(data, 16)));
     return DABX_OK;

@@ -56,7 +56,7 @@ def lib():
 class TxCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("eid", C.c_int32), ("n_frames", C.c_int32), ("n_subch", C.c_int32),
                 ("delay", C.c_int32), ("loop", C.c_int32), ("fmt", C.c_int32), ("snr_db", C.c_double),
-                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64), ("payload_given", C.c_int32), ("tii_main", C.c_int32), ("tii_sub", C.c_int32), ("extra_figs", C.c_int32)]
+                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64), ("payload_given", C.c_int32), ("tii_main", C.c_int32), ("tii_sub", C.c_int32), ("extra_figs", C.c_int32), ("packet_sub", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -94,7 +94,7 @@ def subch_layout(n=18, kbps=64, option=0, level=3):
 
 
 def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0, snr_db=30.0, cfo_hz=0.0,
-                rms=28.0, payload=None, tii=None, extra_figs=False):
+                rms=28.0, payload=None, tii=None, extra_figs=False, packet_sub=0):
     """Synthetic Mode-I signal.  Returns (iq, fib[n_frames,12,32], msc[n_frames*4, bytes_per_cif]).
     payload: optional uint8 array [n_frames*4, bytes_per_cif] to transmit instead of random bytes."""
     L = lib()
@@ -104,6 +104,7 @@ def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0
     cfg.snr_db, cfg.cfo_hz, cfg.rms = snr_db, cfo_hz, rms
     cfg.tii_main, cfg.tii_sub = (tii if tii is not None else (-1, 0))
     cfg.extra_figs = 1 if extra_figs else 0
+    cfg.packet_sub = int(packet_sub)
     for i, s in enumerate(subch):
         for j in range(4):
             cfg.subch[i][j] = int(s[j])

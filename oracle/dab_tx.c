@@ -28,6 +28,8 @@ typedef struct {
     int32_t  payload_given;/* 1: msc_out already holds the payload to transmit    */
     int32_t  tii_main, tii_sub; /* TII in every null symbol (EN 300 401 §14.8); main < 0: none */
     int32_t  extra_figs;   /* 1: also send FIG 0/5, 0/8, 0/13, 0/17, 0/18, 0/19 for the first service */
+    int32_t  packet_sub;   /* >= 1: this sub-channel is a packet-mode data component (SCId 0x200 + index, packet address 0x155,
+                              user application 7 = SPI) of the FIRST service, announced by FIG 0/2 (TMId 3), 0/3 and 0/13; 0 = none */
 } dab_tx_cfg_t;
 
 /* ---- deterministic PRNG (splitmix64) ---- */
@@ -93,18 +95,38 @@ static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *f
         }
         f->b[0] = (uint8_t)(f->len - 1);
     }
-    /* FIG 0/2 basic service organisation: one DAB+ audio service per sub-channel */
-    for (int s0 = 0; s0 < c->n_subch; s0 += 5) {
+    /* FIG 0/2 basic service organisation: one audio service per sub-channel; a packet-mode sub-channel
+     * (cfg.packet_sub) is instead the second component of the first service */
+    const int pk = c->packet_sub > 0 && c->packet_sub < c->n_subch ? c->packet_sub : 0;
+    for (int s = 0; s < c->n_subch;) {
         fig_t *f = &figs[n++];
-        int cnt = c->n_subch - s0 < 5 ? c->n_subch - s0 : 5;
-        f->b[0] = (uint8_t)(1 + 5 * cnt); f->b[1] = 0x02; f->len = 2;
-        for (int s = s0; s < s0 + cnt; s++) {
-            int sid = 0x1A01 + s;
+        f->b[1] = 0x02; f->len = 2;
+        while (s < c->n_subch && f->len + 7 <= 30) {
+            if (s == pk && pk) { ++s; continue; }
+            int sid = 0x1A01 + s, two = (s == 0 && pk);
             f->b[f->len++] = (uint8_t)(sid >> 8); f->b[f->len++] = (uint8_t)sid;
-            f->b[f->len++] = 0x01;                           /* one component      */
+            f->b[f->len++] = (uint8_t)(two ? 0x02 : 0x01);   /* number of components */
             f->b[f->len++] = (uint8_t)(c->subch[s][1] == 2 ? 0x00 : 0x3F);   /* TMId 0; ASCTy 0 (MP2) on UEP, 63 (DAB+) on EEP */
             f->b[f->len++] = (uint8_t)((s << 2) | 0x02);     /* SubChId, primary   */
+            if (two) {
+                int scid = 0x200 + pk;
+                f->b[f->len++] = (uint8_t)(0xC0 | (scid >> 6));          /* TMId 3, SCId */
+                f->b[f->len++] = (uint8_t)((scid & 0x3F) << 2);          /* secondary, no CA */
+            }
+            ++s;
         }
+        f->b[0] = (uint8_t)(f->len - 1);
+    }
+    if (pk) {
+        int scid = 0x200 + pk, addr = 0x155;
+        { fig_t *f = &figs[n++];                              /* FIG 0/3: SCId, DG used, DSCTy 60 (MOT), SubChId, packet address */
+          f->b[0] = 0x06; f->b[1] = 0x03; f->b[2] = (uint8_t)(scid >> 4); f->b[3] = (uint8_t)((scid & 0xF) << 4);
+          f->b[4] = 60; f->b[5] = (uint8_t)((pk << 2) | (addr >> 8)); f->b[6] = (uint8_t)addr; f->len = 7; }
+        { fig_t *f = &figs[n++];                              /* FIG 0/8: SCIdS 1 <-> SCId (long form) */
+          f->b[0] = 0x06; f->b[1] = 0x08; f->b[2] = 0x1A; f->b[3] = 0x01; f->b[4] = 0x01;
+          f->b[5] = (uint8_t)(0x80 | (scid >> 8)); f->b[6] = (uint8_t)scid; f->len = 7; }
+        { fig_t *f = &figs[n++];                              /* FIG 0/13: SCIdS 1, one application: SPI (type 7), no data */
+          f->b[0] = 0x06; f->b[1] = 0x0D; f->b[2] = 0x1A; f->b[3] = 0x01; f->b[4] = 0x11; f->b[5] = 0x00; f->b[6] = 0xE0; f->len = 7; }
     }
     { /* FIG 0/9: LTO +1 h, ECC 0xE2, international table 1 */
         fig_t *f = &figs[n++];
@@ -128,6 +150,7 @@ static int build_figs(const dab_tx_cfg_t *c, const dab_profile_t *prof, fig_t *f
         memcpy(f->b + 4, lab, 16); f->b[20] = 0xFF; f->b[21] = 0x00; f->len = 22;
     }
     for (int s = 0; s < c->n_subch; s++) { /* FIG 1/1 programme service labels */
+        if (pk && s == pk) continue;
         fig_t *f = &figs[n++];
         int sid = 0x1A01 + s;
         char lab[17];

@@ -351,3 +351,110 @@ def test_service_selection_delivers_dabplus_access_units():
             break
         i += 1
     assert msg.decode("latin-1") == dl_text
+
+
+def test_audio_and_packet_data_component_side_by_side():
+    """the reference runs an audio decoder and data decoders at once (dabsdrDecoderId_t): select the DAB+ audio component
+    and the packet-mode SPI component of the same service; access units and MSC data groups both arrive."""
+    from tests.test_packet_mode import frames_of, packets
+    L = aa.load_library()
+    sub = [[0, 0, 3, 64], [48, 0, 3, 32]]
+    n_frames = 30
+    sf_rows, aus_tx = ob.superframes(64, n_frames * 4 // 5, seed=21)
+    rng = np.random.default_rng(9)
+    groups = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(30, 400, 40)]
+    pk = []
+    for i, g in enumerate(groups):
+        pk += packets(g, 0x155, 48 if i % 2 else 24, ci0=i)
+        pk += packets(bytes(rng.integers(0, 256, 50, dtype=np.uint8)), 0x2AA, 24)      # another address on the same sub-channel
+    prows = frames_of(pk, 96)[:n_frames * 4]
+    payload = np.zeros((n_frames * 4, 192 + 96), dtype=np.uint8)
+    payload[:len(sf_rows), :192] = sf_rows
+    payload[:len(prows), 192:] = prows
+    sent = len(prows)
+    iq, _, _ = ob.tx_generate(seed=79, eid=0x1236, n_frames=n_frames, subch=sub, delay=2500, snr_db=22.0, cfo_hz=300.0,
+                              payload=payload, packet_sub=1)
+    samples = iq.astype(np.float32) - 128.0
+    pos, gate = [0], threading.Event()
+    aus, dgs, events, lock = [], [], [], threading.Lock()
+    handle = C.c_void_p()
+
+    class AudioCB(C.Structure):
+        _fields_ = [("id", C.c_int), ("ASCTy", C.c_uint8), ("header", C.c_uint8), ("auLen", C.c_uint16), ("pAuData", C.POINTER(C.c_uint8))]
+
+    class DgCB(C.Structure):
+        _fields_ = [("id", C.c_int), ("SCId", C.c_uint16), ("userAppType", C.c_uint16), ("dgLen", C.c_uint16), ("pDgData", C.POINTER(C.c_uint8))]
+
+    @C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint16)
+    def get_samples(buf, n):
+        if pos[0] >= 2 * 8 * 196608 and not gate.is_set():
+            gate.wait(0.05)
+        out = np.ctypeslib.as_array(buf, shape=(2 * n,))
+        take = samples[pos[0]:pos[0] + 2 * n]
+        out[:len(take)] = take
+        out[len(take):] = 0.0
+        pos[0] += 2 * n
+
+    @C.CFUNCTYPE(None, C.POINTER(Ntf), C.c_void_p)
+    def on_ntf(p, ctx):
+        with lock:
+            events.append((p.contents.nid, p.contents.status))
+
+    @C.CFUNCTYPE(None, C.POINTER(AudioCB), C.c_void_p)
+    def on_audio(p, ctx):
+        a = p.contents
+        with lock:
+            aus.append((a.id, bytes(np.ctypeslib.as_array(a.pAuData, shape=(a.auLen,)))))
+
+    @C.CFUNCTYPE(None, C.POINTER(DgCB), C.c_void_p)
+    def on_dg(p, ctx):
+        d = p.contents
+        with lock:
+            dgs.append((d.id, d.SCId, d.userAppType, bytes(np.ctypeslib.as_array(d.pDgData, shape=(d.dgLen,)))))
+
+    L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
+    assert L.dabsdrInit(C.byref(handle)) == 0
+    for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        getattr(L, name)(handle, C.cast(get_samples, C.c_void_p))
+    for name, fn in (("dabsdrRegisterNotificationCb", on_ntf), ("dabsdrRegisterAudioCb", on_audio), ("dabsdrRegisterDataGroupCb", on_dg)):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        getattr(L, name)(handle, C.cast(fn, C.c_void_p), None)
+    L.dabsdr.argtypes = [C.c_void_p]
+    L.dabsdrRequest_Tune.argtypes = [C.c_void_p, C.c_uint32]
+    L.dabsdrRequest_ServiceSelection.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8, C.c_int]
+    L.dabsdrRequest_ServiceStop.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8, C.c_int]
+    L.dabsdrRequest_Exit.argtypes = [C.c_void_p]
+    L.dabsdr(handle)
+    L.dabsdrRequest_Tune(handle, 225648)
+
+    def wait_until(pred, timeout=60.0):
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            with lock:
+                if pred():
+                    return
+            time.sleep(0.02)
+        raise AssertionError(f"timeout: events={events[-8:]} n_au={len(aus)} n_dg={len(dgs)}")
+
+    wait_until(lambda: (NID["SYNC_STATUS"], 0) in events)
+    time.sleep(0.5)
+    L.dabsdrRequest_ServiceSelection(handle, 0x1A01, 0, 0)            # audio, primary decoder
+    L.dabsdrRequest_ServiceSelection(handle, 0x1A01, 1, -1)           # SCIdS 1: the packet component, data decoder
+    wait_until(lambda: events.count((NID["SERVICE_SELECTION"], 0)) == 2)
+    gate.set()
+    wait_until(lambda: len(aus) >= 18 and len(dgs) >= 8)
+    L.dabsdrRequest_ServiceStop(handle, 0x1A01, 1, -1)
+    wait_until(lambda: (9, 0) in events)                               # DABSDR_NID_SERVICE_STOP
+    L.dabsdrRequest_Exit(handle)
+    L.dabsdrDeinit.argtypes = [C.POINTER(C.c_void_p)]
+    L.dabsdrDeinit(C.byref(handle))
+    with lock:
+        got_dg, got_au = list(dgs), list(aus)
+    assert all(g[0] == -1 and g[1] == 0x201 and g[2] == 7 for g in got_dg)
+    first = groups.index(got_dg[0][3])                                 # first group complete after the selection took effect
+    assert [g[3] for g in got_dg] == groups[first:first + len(got_dg)] and sent > 0
+    tx = [a.tobytes() for a in aus_tx]
+    k0 = tx.index(got_au[0][1])
+    n_cmp = min(len(got_au), 45)                                        # before the transmission (30 frames) runs out
+    assert n_cmp >= 18 and all(a[0] == 0 for a in got_au) and [a[1] for a in got_au[:n_cmp]] == tx[k0:k0 + n_cmp]   # no gap at the stop
