@@ -30,61 +30,63 @@ struct Gf {                          // GF(2^8), p(x) = x^8 + x^4 + x^3 + x^2 + 
     __device__ uint8_t pow(int e) const { return exp[((e % 255) + 255) % 255]; }
 };
 
+// Scratch of the (rare) error correction of one code word, in LDS rather than registers: kept in VGPRs these
+// arrays would cap how many workgroups fit a CU for a path that almost never runs.
+struct RsWork { uint8_t C[11], B[11], Tp[11], Om[10], fix[5], pos[5]; };
+
 // Correct one code word whose syndromes S[0..9] are not all zero.  cw(k) = sf[j + k s], k = 0 the highest
 // power.  Returns the number of corrected bytes, -1 when uncorrectable (nothing written then).
-__device__ int rs_correct(const Gf &G, uint8_t *sf, int j, int s, const uint8_t *S)
+__device__ __noinline__ int rs_correct(const Gf &G, uint8_t *sf, int j, int s, const uint8_t *S, RsWork &w)
 {
     constexpr int N = 120, T2 = 10;
-    uint8_t C[T2 + 1] = {1}, B[T2 + 1] = {1}, b = 1;
+    uint8_t b = 1;
+    for (int i = 0; i <= T2; ++i) { w.C[i] = i == 0; w.B[i] = i == 0; }
     int L = 0, m = 1;
     for (int n = 0; n < T2; ++n) {                       // Berlekamp-Massey
         uint8_t d = S[n];
-        for (int i = 1; i <= L; ++i) d ^= G.mul(C[i], S[n - i]);
+        for (int i = 1; i <= L; ++i) d ^= G.mul(w.C[i], S[n - i]);
         if (!d) { ++m; continue; }
-        uint8_t Tp[T2 + 1];
-        for (int i = 0; i <= T2; ++i) Tp[i] = C[i];
+        for (int i = 0; i <= T2; ++i) w.Tp[i] = w.C[i];
         const uint8_t coef = G.div(d, b);
-        for (int i = 0; i + m <= T2; ++i) C[i + m] ^= G.mul(coef, B[i]);
+        for (int i = 0; i + m <= T2; ++i) w.C[i + m] ^= G.mul(coef, w.B[i]);
         if (2 * L <= n) {
             L = n + 1 - L;
-            for (int i = 0; i <= T2; ++i) B[i] = Tp[i];
+            for (int i = 0; i <= T2; ++i) w.B[i] = w.Tp[i];
             b = d; m = 1;
         } else ++m;
     }
     if (L > T2 / 2) return -1;
-    int pos[T2 / 2], nerr = 0;
+    int nerr = 0;
     for (int k = 0; k < N; ++k) {                        // Chien search over the 120 positions of the shortened code
         const int p = N - 1 - k;
         uint8_t v = 0;
-        for (int i = 0; i <= L; ++i) v ^= G.mul(C[i], G.pow(-p * i));
-        if (!v) { if (nerr == T2 / 2) return -1; pos[nerr++] = k; }
+        for (int i = 0; i <= L; ++i) v ^= G.mul(w.C[i], G.pow(-p * i));
+        if (!v) { if (nerr == T2 / 2) return -1; w.pos[nerr++] = static_cast<uint8_t>(k); }
     }
     if (nerr != L) return -1;
-    uint8_t Om[T2];
     for (int i = 0; i < T2; ++i) {
         uint8_t o = 0;
-        for (int q = 0; q <= L && q <= i; ++q) o ^= G.mul(S[i - q], C[q]);
-        Om[i] = o;
+        for (int q = 0; q <= L && q <= i; ++q) o ^= G.mul(S[i - q], w.C[q]);
+        w.Om[i] = o;
     }
-    uint8_t fix[T2 / 2];
     for (int e = 0; e < nerr; ++e) {                     // Forney, first consecutive root alpha^0
-        const int p = N - 1 - pos[e];
+        const int p = N - 1 - w.pos[e];
         const uint8_t Xinv = G.pow(-p);
         uint8_t num = 0, den = 0;
-        for (int i = T2 - 1; i >= 0; --i) num = static_cast<uint8_t>(G.mul(num, Xinv) ^ Om[i]);
-        for (int i = 1; i <= L; i += 2) den ^= G.mul(C[i], G.pow(-p * (i - 1)));
+        for (int i = T2 - 1; i >= 0; --i) num = static_cast<uint8_t>(G.mul(num, Xinv) ^ w.Om[i]);
+        for (int i = 1; i <= L; i += 2) den ^= G.mul(w.C[i], G.pow(-p * (i - 1)));
         if (!den) return -1;
-        fix[e] = G.mul(G.div(num, den), G.pow(p));
+        w.fix[e] = G.mul(G.div(num, den), G.pow(p));
     }
     for (int e = 0; e < nerr; ++e)
-        if (pos[e] < 110) sf[j + pos[e] * s] ^= fix[e];  // only the data part is kept (parity bytes are dropped anyway)
+        if (w.pos[e] < 110) sf[j + w.pos[e] * s] ^= w.fix[e];   // only the data part is kept (parity bytes are dropped anyway)
     return nerr;
 }
 
 }  // namespace
 
 // max_rec: record slots per sub-channel and step
-__global__ __launch_bounds__(SF_THREADS) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
+__global__ __launch_bounds__(SF_THREADS, 8) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
                                                     uint8_t *data, const uint8_t *__restrict__ gf_tab, int n_frames, int max_rec)
 {
     __shared__ uint8_t t_exp[512], t_log[256];
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_superframe(DevCtx C, const DevSf
     __shared__ int16_t ch_first[8];                      // first chunk of access unit a (ch_first[num] = total)
     __shared__ __attribute__((aligned(16))) uint8_t sf[2880 + 16];
     __shared__ uint8_t synd[24 * 10];
+    __shared__ RsWork rs_work[24];
     __shared__ int res[24];
     __shared__ int sh_ok, sh_num;
     __shared__ uint16_t sh_start[8];
@@ -173,10 +176,9 @@ __global__ __launch_bounds__(SF_THREADS) void k_superframe(DevCtx C, const DevSf
         }
         __syncthreads();
         if (t < s) {
-            uint8_t S[10];
             bool clean = true;
-            for (int r = 0; r < 10; ++r) { S[r] = synd[10 * t + r]; clean = clean && S[r] == 0; }
-            res[t] = clean ? 0 : rs_correct(G, sf, t, s, S);
+            for (int r = 0; r < 10; ++r) clean = clean && synd[10 * t + r] == 0;
+            res[t] = clean ? 0 : rs_correct(G, sf, t, s, synd + 10 * t, rs_work[t]);
         }
         __syncthreads();
         if (t == 0) {
