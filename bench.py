@@ -32,6 +32,7 @@ SYMS_PER_FRAME = 76
 # algorithmic HBM bytes per ensemble-frame (SURVEY.md §8d, u8 input, int8 soft bits)
 BYTES_CHAIN = 393216 + 230400 + 230400 + 14208          # IQ read + soft write + soft read + decoded bytes
 BYTES_VITERBI = 230400 + 14208                          # dominant kernel: soft-bit read + decoded bytes
+BYTES_DEMOD = 387904 + 230400                           # k_demod: IQ of the 76 data/reference symbols + soft-bit write
 ACS_PER_FRAME = (4 * 774 + 4 * 18 * 1542) * 64          # trellis steps x 64 states, 18 x 48 CU EEP 3-A
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9               # 256 CU x 4 SIMD-32 x 2.4 GHz
@@ -299,6 +300,9 @@ def main():
                          "decision_scratch_bytes_per_launch": 2 * 8 * S * F * (4 * 774 + 4 * args.nsub * 1542),
                          "acs_per_s": round(acs_rate, 0),
                          "chain_algorithmic_GBps": round(value / world / FRAME_S * BYTES_CHAIN / 1e9, 2)},
+            "other_kernels": {"k_demod": {"bound": "hbm", "algorithmic_bytes_per_launch": S * F * BYTES_DEMOD,
+                                          "achieved": round(S * F * BYTES_DEMOD / (phase_ms[1] / args.steps * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                          "frac": round(S * F * BYTES_DEMOD / (phase_ms[1] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "setup_s": {"synthesis": round(t_gen, 1)},
         }
         if args.dabplus:
