@@ -216,6 +216,36 @@ def test_pinned_overlapped_ingest_matches_oracle(gpu_ctx_factory):
     ctx.free_pinned(stage)
 
 
+def test_push_all_out_of_lock_step_and_argument_checks(gpu_ctx_factory):
+    """dabx_push_all falls back to one copy per stream when the streams do not stand at the same write position; the
+    result is the same as pushing each stream on its own"""
+    sub = ob.subch_layout(1, 64)
+    sigs = [ob.tx_generate(seed=400 + s, n_frames=5, subch=sub, delay=300 * s, snr_db=20.0)[0] for s in range(2)]
+    n = min(len(x) for x in sigs) // 2
+    sigs = [x[:2 * n] for x in sigs]
+    ctx = gpu_ctx_factory(n_streams=2, fmt=0, ring_frames=8, max_frames=2)
+    stage = ctx.alloc_pinned(2 * n * 2)
+    for s in range(2):
+        stage[s * n * 2:(s + 1) * n * 2] = sigs[s]
+        ctx.set_subchannels(s, sub)
+    ctx.push(1, sigs[1][:2 * 1000])                                     # stream 1 runs 1000 samples ahead
+    ctx.push_all(stage.ctypes.data, n * 2, 1000, kind=2)                # ... both advance by 1000: out of lock step -> per-stream copies
+    ctx.push_pinned(0, stage.ctypes.data + 2 * 1000, n - 1000)
+    ctx.push_pinned(1, stage.ctypes.data + n * 2 + 2 * 2000, n - 2000)
+    # stream 1 now holds samples [0,1000) + [0,1000) again + [2000,n): a corrupted stream by construction; stream 0 is intact
+    ctx.process(2)
+    orc = ob.Stream(subch=sub, ring_len=ctx.ring_samples)
+    orc.push(sigs[0])
+    o = orc.process(2)
+    gf, gok = ctx.fib(0)
+    assert gok.all() and np.array_equal(gf, o["fib"]) and np.array_equal(ctx.sync(0), o["sync"])
+    with pytest.raises(aa.DabxError):
+        ctx.push_all(stage.ctypes.data, n * 2, 10 * ob.TF, kind=2)      # overrun is refused before anything is copied
+    with pytest.raises(aa.DabxError):
+        ctx.push_all(stage.ctypes.data, n * 2, 16, kind=7)
+    ctx.free_pinned(stage)
+
+
 def test_null_spectrum_matches_oracle_and_carries_tii(gpu_ctx_factory):
     import ctypes as C
     sub = ob.subch_layout(2, 64)
