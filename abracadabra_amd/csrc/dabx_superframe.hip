@@ -9,9 +9,11 @@
 // One workgroup per (stream, sub-channel).  The logical frames of a step (the sub-channel's slice of every
 // valid CIF record k_viterbi wrote) are appended to the <= 4 frames carried over from the step before;
 // a window of five frames slides over that sequence exactly as a serial receiver would: decoded -> advance
-// by five, rejected -> advance by one.  Inside a window the work is parallel: 10 s syndromes on 10 s
-// threads, one thread per code word for the (rare) Berlekamp-Massey / Chien / Forney correction, one thread
-// per access unit for the CRC.
+// by five, rejected -> advance by one.  While the stream is synchronised up to SF_BATCH windows (positions
+// i, i+5, ...) are worked on together: 10 s syndromes per window as independent look-up sums, one thread per
+// code word for the (rare) Berlekamp-Massey / Chien / Forney correction, the access-unit CRCs in 32-byte chunks.
+// The windows up to the first one that fails its fire code are accepted; a failing window is then taken up
+// again on its own, so the outcome is exactly the serial receiver's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,6 +22,8 @@
 namespace {
 
 constexpr int CRC_CHUNK = 32;
+constexpr int SF_BATCH = 4;         // windows per pass while synchronised
+constexpr int SF_WIN = 2880 + 16;   // LDS bytes per window
 constexpr int SF_THREADS = 128;      // two waves: at most 96 chunks / 10 s syndromes are in flight at once, and more workgroups fit a CU
 
 struct Gf {                          // GF(2^8), p(x) = x^8 + x^4 + x^3 + x^2 + 1, tables in LDS
@@ -86,20 +90,20 @@ __device__ __noinline__ int rs_correct(const Gf &G, uint8_t *sf, int j, int s, c
 }  // namespace
 
 // max_rec: record slots per sub-channel and step
-__global__ __launch_bounds__(SF_THREADS, 8) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
+__global__ __launch_bounds__(SF_THREADS, 4) void k_superframe(DevCtx C, const DevSfSub *__restrict__ subs, DevSfState *state, DevSfRec *recs,
                                                     uint8_t *data, const uint8_t *__restrict__ gf_tab, int n_frames, int max_rec)
 {
     __shared__ uint8_t t_exp[512], t_log[256];
     __shared__ uint16_t t_crc[256], t_fire[256], t_shift[16];
-    __shared__ uint16_t ch_crc[96];                      // CRC of every 32-byte chunk of the access units
-    __shared__ int16_t ch_first[8];                      // first chunk of access unit a (ch_first[num] = total)
-    __shared__ __attribute__((aligned(16))) uint8_t sf[2880 + 16];
-    __shared__ uint8_t synd[24 * 10];
+    __shared__ uint16_t ch_crc[SF_BATCH * 96];           // CRC of every 32-byte chunk of the access units
+    __shared__ int16_t ch_first[SF_BATCH * 8 + 1];       // first chunk of access unit a of window w at [8 w + a]; [8 nb] = total
+    __shared__ __attribute__((aligned(16))) uint8_t sfa[SF_BATCH * SF_WIN];
+    __shared__ uint8_t synd[SF_BATCH * 240];
     __shared__ RsWork rs_work[24];
-    __shared__ int res[24];
-    __shared__ int sh_ok, sh_num;
-    __shared__ uint16_t sh_start[8];
-    __shared__ int sh_auflag[8];
+    __shared__ int res[SF_BATCH * 24];
+    __shared__ int sh_ok[SF_BATCH], sh_num[SF_BATCH], sh_acc;
+    __shared__ uint16_t sh_start[SF_BATCH * 8];
+    __shared__ int sh_auflag[SF_BATCH * 8];
 
     const int t = threadIdx.x;
     const DevSfSub sb = subs[blockIdx.x];
@@ -142,27 +146,35 @@ __global__ __launch_bounds__(SF_THREADS, 8) void k_superframe(DevCtx C, const De
 
     int i = 0, out = 0, synced = stt.synced;
     uint32_t n_sf = 0, n_auok = 0, n_aubad = 0, n_corr = 0, n_fail = 0, n_loss = 0;      // meaningful in thread 0
+    const int wpf = fb >> 2, wpw = 5 * wpf;              // 32-bit words per frame / per window (frames are multiples of 24 bytes)
     while (i + 5 <= total) {
-        {   // the window as 32-bit words (frames are multiples of 24 bytes): up to six loads in flight per thread
-            const int wpf = fb >> 2, nw = 5 * wpf;
-            uint32_t w[6];
+        const int nb = synced ? min(SF_BATCH, (total - i) / 5) : 1;
+        // ---- windows i, i+5, ... into LDS, six loads in flight per thread
+        for (int b0 = 0; b0 < nb * wpw; b0 += 6 * SF_THREADS) {
+            uint32_t wv[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int idx = t + SF_THREADS * u;
-                if (idx < nw) {
-                    const int f = idx / wpf, o = idx - f * wpf;
-                    w[u] = reinterpret_cast<const uint32_t *>(frame_ptr(i + f))[o];
+                const int idx = b0 + t + SF_THREADS * u;
+                if (idx < nb * wpw) {
+                    const int f = idx / wpf, o = idx - f * wpf;          // f counts frames from i on: windows are contiguous
+                    wv[u] = reinterpret_cast<const uint32_t *>(frame_ptr(i + f))[o];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 6; ++u)
-                if (t + SF_THREADS * u < nw) reinterpret_cast<uint32_t *>(sf)[t + SF_THREADS * u] = w[u];
+            for (int u = 0; u < 6; ++u) {
+                const int idx = b0 + t + SF_THREADS * u;
+                if (idx < nb * wpw) {
+                    const int w = idx / wpw;
+                    reinterpret_cast<uint32_t *>(sfa + w * SF_WIN)[idx - w * wpw] = wv[u];
+                }
+            }
         }
         __syncthreads();
-        // ---- RS(120,110): syndrome r of code word j is item 10 j + r
-        for (int q = t; q < 10 * s; q += SF_THREADS) {
+        // ---- RS(120,110): syndrome r of code word j of window w is item (w, 10 j + r)
+        for (int q = t; q < nb * 10 * s; q += SF_THREADS) {
             // S_r = sum_k c_k alpha^(r (119 - k)): 120 independent table look-ups instead of a Horner chain
-            const int j = q / 10, r = q % 10;
+            const int w = q / (10 * s), jr = q - w * 10 * s, j = jr / 10, r = jr % 10;
+            const uint8_t *sf = sfa + w * SF_WIN;
             unsigned acc = 0;
             int e = (r * 119) % 255;
 #pragma unroll 8
@@ -172,113 +184,141 @@ __global__ __launch_bounds__(SF_THREADS, 8) void k_superframe(DevCtx C, const De
                 e -= r;
                 e += e < 0 ? 255 : 0;
             }
-            synd[q] = static_cast<uint8_t>(acc);
+            synd[w * 240 + jr] = static_cast<uint8_t>(acc);
         }
         __syncthreads();
-        if (t < s) {
-            bool clean = true;
-            for (int r = 0; r < 10; ++r) clean = clean && synd[10 * t + r] == 0;
-            res[t] = clean ? 0 : rs_correct(G, sf, t, s, synd + 10 * t, rs_work[t]);
-        }
+        if (t < s)
+            for (int w = 0; w < nb; ++w) {
+                const uint8_t *S = synd + w * 240 + 10 * t;
+                bool clean = true;
+                for (int r = 0; r < 10; ++r) clean = clean && S[r] == 0;
+                res[w * 24 + t] = clean ? 0 : rs_correct(G, sfa + w * SF_WIN, t, s, S, rs_work[t]);
+            }
         __syncthreads();
-        if (t == 0) {
-            unsigned c = 0;                               // fire code over bytes 2..10
+        if (t < nb) {                                     // one window per thread: fire code over bytes 2..10, header
+            const uint8_t *sf = sfa + t * SF_WIN;
+            unsigned c = 0;
             for (int k = 2; k < 11; ++k) c = ((c << 8) ^ t_fire[((c >> 8) ^ sf[k]) & 0xFF]) & 0xFFFF;
             const bool ok = c == ((static_cast<unsigned>(sf[0]) << 8) | sf[1]) && !(sf[0] == 0 && sf[1] == 0 && sf[2] == 0);
-            sh_ok = ok;
-            if (ok) {
-                const int dac = (sf[2] >> 6) & 1, sbr = (sf[2] >> 5) & 1;
-                const int num = dac ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
-                sh_num = num;
-                sh_start[0] = static_cast<uint16_t>(dac ? (sbr ? 6 : 11) : (sbr ? 5 : 8));
-                for (int a = 1; a < num; ++a) {           // 12-bit big-endian fields packed from byte 3
-                    const int bit = 24 + 12 * (a - 1), byte = bit >> 3;
-                    sh_start[a] = static_cast<uint16_t>((bit & 4) ? (((sf[byte] & 0x0F) << 8) | sf[byte + 1]) : ((sf[byte] << 4) | (sf[byte + 1] >> 4)));
-                }
-                sh_start[num] = static_cast<uint16_t>(110 * s);
-                for (int a = num + 1; a < 8; ++a) sh_start[a] = 0;
-                int nch = 0;                              // chunks of the access units with sane bounds
-                for (int a = 0; a < num; ++a) {
-                    ch_first[a] = static_cast<int16_t>(nch);
-                    const int a0 = sh_start[a], a1 = sh_start[a + 1], len = a1 - a0;
-                    if (!(a0 < sh_start[0] || len < 3 || a1 > 110 * s)) nch += (len - 2 + CRC_CHUNK - 1) / CRC_CHUNK;
-                }
-                ch_first[num] = static_cast<int16_t>(nch);
+            sh_ok[t] = ok;
+            const int dac = (sf[2] >> 6) & 1, sbr = (sf[2] >> 5) & 1;
+            const int num = dac ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
+            sh_num[t] = num;
+            uint16_t *st8 = sh_start + 8 * t;
+            st8[0] = static_cast<uint16_t>(dac ? (sbr ? 6 : 11) : (sbr ? 5 : 8));
+            for (int a = 1; a < num; ++a) {               // 12-bit big-endian fields packed from byte 3
+                const int bit = 24 + 12 * (a - 1), byte = bit >> 3;
+                st8[a] = static_cast<uint16_t>((bit & 4) ? (((sf[byte] & 0x0F) << 8) | sf[byte + 1]) : ((sf[byte] << 4) | (sf[byte + 1] >> 4)));
             }
+            st8[num] = static_cast<uint16_t>(110 * s);
+            for (int a = num + 1; a < 8; ++a) st8[a] = 0;
         }
         __syncthreads();
-        if (!sh_ok) {                                     // not a super frame boundary (or damaged): slide by one frame
+        if (t == 0) {                                     // accepted: the windows before the first fire code failure
+            int acc = 0;
+            while (acc < nb && sh_ok[acc]) ++acc;
+            sh_acc = acc;
+            int nch = 0;                                  // chunks of the access units with sane bounds
+            for (int w = 0; w < acc; ++w) {
+                const uint16_t *st8 = sh_start + 8 * w;
+                for (int a = 0; a < 8; ++a) {
+                    ch_first[8 * w + a] = static_cast<int16_t>(nch);
+                    if (a >= sh_num[w]) continue;
+                    const int a0 = st8[a], a1 = st8[a + 1], len = a1 - a0;
+                    if (!(a0 < st8[0] || len < 3 || a1 > 110 * s)) nch += (len - 2 + CRC_CHUNK - 1) / CRC_CHUNK;
+                }
+            }
+            ch_first[8 * acc] = static_cast<int16_t>(nch);
+        }
+        __syncthreads();
+        const int acc = sh_acc;
+        if (acc == 0) {                                   // not a super frame boundary (or damaged): slide by one frame
             if (t == 0 && synced) ++n_loss;
             synced = 0;
             i += 1;
             __syncthreads();
             continue;
         }
-        const int num = sh_num;
-        // CRC-16-CCITT of the access units in 32-byte chunks, one thread per chunk: the FIRST chunk of a unit is the
+        // CRC-16-CCITT of the access units in 32-byte chunks, one chunk per item: the FIRST chunk of a unit is the
         // short one and starts from 0xFFFF, the others are whole and start from 0, so joining them is
         // crc = shift32(crc) ^ crc(chunk) with shift32 = a 16-entry table (the CRC is linear over GF(2))
-        if (t < ch_first[num]) {
-            int a = 0;
-            while (t >= ch_first[a + 1]) ++a;
-            const int a0 = sh_start[a], n = sh_start[a + 1] - a0 - 2, nch = ch_first[a + 1] - ch_first[a], q = t - ch_first[a];
+        for (int q = t; q < ch_first[8 * acc]; q += SF_THREADS) {
+            int wa = 0;
+            while (q >= ch_first[wa + 1]) ++wa;           // (window, access unit) of this chunk; empty entries have equal bounds
+            const int w = wa >> 3, a = wa & 7;
+            const uint8_t *sf = sfa + w * SF_WIN;
+            const int a0 = sh_start[8 * w + a], n = sh_start[8 * w + a + 1] - a0 - 2, nch = ch_first[wa + 1] - ch_first[wa], qq = q - ch_first[wa];
             const int first_len = n - (nch - 1) * CRC_CHUNK;
-            const int beg = q == 0 ? 0 : first_len + (q - 1) * CRC_CHUNK, cnt = q == 0 ? first_len : CRC_CHUNK;
-            unsigned c = q == 0 ? 0xFFFFu : 0u;
+            const int beg = qq == 0 ? 0 : first_len + (qq - 1) * CRC_CHUNK, cnt = qq == 0 ? first_len : CRC_CHUNK;
+            unsigned c = qq == 0 ? 0xFFFFu : 0u;
             for (int k = 0; k < cnt; ++k) c = ((c << 8) ^ t_crc[((c >> 8) ^ sf[a0 + beg + k]) & 0xFF]) & 0xFFFF;
-            ch_crc[t] = static_cast<uint16_t>(c);
+            ch_crc[q] = static_cast<uint16_t>(c);
         }
         __syncthreads();
-        if (t < num) {                                    // one access unit per thread: bounds, then join its chunks
-            const int a0 = sh_start[t], a1 = sh_start[t + 1], len = a1 - a0;
+        if (t < 8 * acc) {                                // one access unit per thread: bounds, then join its chunks
+            const int w = t >> 3, a = t & 7;
             int flag = 0;
-            if (!(a0 < sh_start[0] || len < 3 || a1 > 110 * s)) {
-                unsigned c = ch_crc[ch_first[t]];
-                for (int q = ch_first[t] + 1; q < ch_first[t + 1]; ++q) {
-                    unsigned m = 0;
-                    for (int b = 0; b < 16; ++b) m ^= ((c >> b) & 1u) ? t_shift[b] : 0u;
-                    c = m ^ ch_crc[q];
+            if (a < sh_num[w]) {
+                const uint8_t *sf = sfa + w * SF_WIN;
+                const uint16_t *st8 = sh_start + 8 * w;
+                const int a0 = st8[a], a1 = st8[a + 1], len = a1 - a0;
+                if (!(a0 < st8[0] || len < 3 || a1 > 110 * s)) {
+                    unsigned c = ch_crc[ch_first[t]];
+                    for (int q = ch_first[t] + 1; q < ch_first[t + 1]; ++q) {
+                        unsigned m = 0;
+                        for (int b = 0; b < 16; ++b) m ^= ((c >> b) & 1u) ? t_shift[b] : 0u;
+                        c = m ^ ch_crc[q];
+                    }
+                    c = ~c & 0xFFFF;
+                    flag = 1 | ((c == ((static_cast<unsigned>(sf[a0 + len - 2]) << 8) | sf[a0 + len - 1])) ? 2 : 0);
                 }
-                c = ~c & 0xFFFF;
-                flag = 1 | ((c == ((static_cast<unsigned>(sf[a0 + len - 2]) << 8) | sf[a0 + len - 1])) ? 2 : 0);
             }
             sh_auflag[t] = flag;
         }
         __syncthreads();
-        if (out < max_rec) {
-            uint8_t *dst = data + sb.data_off + (size_t)out * 110 * s;
+        for (int w = 0; w < acc; ++w) {
+            if (out + w >= max_rec) break;
+            uint8_t *dst = data + sb.data_off + (size_t)(out + w) * 110 * s;
+            const uint8_t *sf = sfa + w * SF_WIN;
             for (int b = t; b < 110 * s; b += SF_THREADS) dst[b] = sf[b];
         }
-        if (t == 0) {
+        if (t < acc) {                                    // one record per accepted window
+            const int w = t;
+            const uint8_t *sf = sfa + w * SF_WIN;
             DevSfRec rec = {};
-            rec.first_frame = base + static_cast<uint32_t>(i);
+            rec.first_frame = base + static_cast<uint32_t>(i + 5 * w);
             rec.header = sf[2] & 0x7F;
-            rec.num_aus = static_cast<uint8_t>(num);
+            rec.num_aus = static_cast<uint8_t>(sh_num[w]);
             int corrected = 0, failed = 0;
-            for (int j = 0; j < s; ++j) { if (res[j] < 0) ++failed; else corrected += res[j]; }
+            for (int j = 0; j < s; ++j) { if (res[w * 24 + j] < 0) ++failed; else corrected += res[w * 24 + j]; }
             rec.rs_corrected = static_cast<uint16_t>(corrected);
             rec.rs_failed = static_cast<uint16_t>(failed);
-            for (int a = 0; a < 8; ++a) rec.au_start[a] = sh_start[a];
-            for (int a = 0; a < num; ++a) {
-                if (sh_auflag[a] & 1) rec.au_valid |= static_cast<uint8_t>(1 << a);
-                if (sh_auflag[a] & 2) { rec.au_ok |= static_cast<uint8_t>(1 << a); ++n_auok; } else ++n_aubad;
+            for (int a = 0; a < 8; ++a) rec.au_start[a] = sh_start[8 * w + a];
+            for (int a = 0; a < sh_num[w]; ++a) {
+                if (sh_auflag[8 * w + a] & 1) rec.au_valid |= static_cast<uint8_t>(1 << a);
+                if (sh_auflag[8 * w + a] & 2) rec.au_ok |= static_cast<uint8_t>(1 << a);
             }
-            if (out < max_rec) recs[sb.rec_off + out] = rec;
-            ++n_sf; n_corr += corrected; n_fail += failed;
+            if (out + w < max_rec) recs[sb.rec_off + out + w] = rec;
         }
-        ++out;
+        if (t == 0)
+            for (int w = 0; w < acc; ++w) {
+                ++n_sf;
+                for (int j = 0; j < s; ++j) { if (res[w * 24 + j] < 0) ++n_fail; else n_corr += static_cast<uint32_t>(res[w * 24 + j]); }
+                for (int a = 0; a < sh_num[w]; ++a) { if (sh_auflag[8 * w + a] & 2) ++n_auok; else ++n_aubad; }
+            }
+        out += acc;
         synced = 1;
-        i += 5;
+        i += 5 * acc;
         __syncthreads();
     }
     // ---- carry the unconsumed frames (< 5) over to the next step, staged through LDS: the source may be the carry buffer itself
     const int left = total - i;
     for (int f = 0; f < left; ++f) {
         const uint8_t *src = frame_ptr(i + f);
-        for (int b = t; b < fb; b += SF_THREADS) sf[f * fb + b] = src[b];
+        for (int b = t; b < fb; b += SF_THREADS) sfa[f * fb + b] = src[b];
     }
     __syncthreads();
-    for (int b = t; b < left * fb; b += SF_THREADS) stt.buf[b] = sf[b];
+    for (int b = t; b < left * fb; b += SF_THREADS) stt.buf[b] = sfa[b];
     if (t == 0) {
         stt.carry = left;
         stt.synced = synced;
