@@ -492,6 +492,41 @@ void after_step(dabsdr_s *h)
     const double sig = static_cast<double>(rec.e_sig);
     if (noise > 0 && sig > noise) snr10 = static_cast<int16_t>(std::min(600L, std::lround(100.0 * std::log10((sig - noise) / noise))));
     else if (sig > 0 && noise <= 0) snr10 = 600;
+    if (h->db.reconfigured) {                             // multiplex reconfiguration took effect (EN 300 401 §6.5)
+        h->db.reconfigured = false;
+        notify(h, DABSDR_NID_RECONFIGURATION, DABSDR_NSTAT_SUCCESS, nullptr, 0);
+        // running selections follow their component into the new configuration; one whose component is gone stops
+        std::vector<std::unique_ptr<Selection>> keep;
+        for (auto &sp : h->sel) {
+            bool found = false;
+            if (const figdb::Service *sv = h->db.find_service(sp->sid))
+                for (const auto &c : sv->comp) {
+                    if (c.scids != sp->scids) continue;
+                    int subch = c.subch;
+                    if (c.tmid == 3) {
+                        auto pi = h->db.packet.find(c.scid);
+                        if (pi == h->db.packet.end()) break;
+                        subch = pi->second.subch;
+                        sp->pkt.address = pi->second.packet_address;
+                    }
+                    auto it = h->db.subch.find(subch);
+                    if (it == h->db.subch.end()) break;
+                    sp->kbps = it->second.kbps;
+                    sp->subch_id = subch;
+                    sp->sub = {it->second.start, it->second.option, it->second.level, it->second.kbps};
+                    if (!it->second.long_form) sp->sub = {it->second.start, 2, it->second.uep_index, 0};
+                    found = true;
+                    break;
+                }
+            if (found) keep.push_back(std::move(sp));
+            else {
+                dabsdrNtfServiceStop_t stop = {sp->sid, static_cast<uint8_t>(sp->scids), sp->id};
+                notify(h, DABSDR_NID_SERVICE_STOP, DABSDR_NSTAT_SUCCESS, &stop, sizeof stop);
+            }
+        }
+        h->sel = std::move(keep);
+        apply_selections(h);
+    }
     for (uint32_t sid : h->db.pty_changed)                // FIG 0/17 -> DABSDR_NID_PTY (dabsdr.h:353-357)
         if (const figdb::Service *sv = h->db.find_service(sid)) {
             dabsdrNtfPTy_t p = {sid, static_cast<uint8_t>(sv->pty), static_cast<uint8_t>(sv->pty)};
@@ -871,6 +906,8 @@ DABSDR_API int dabsdr_amd_fig_dump(const uint8_t *fibs, int n_fibs, char *out, i
                       kv.second.new_flag ? 1 : 0);
         s += line;
     }
+    std::snprintf(line, sizeof line, "reconfiguration pending=%d next=%d applied=%d\n", db.change_pending ? 1 : 0, db.next ? 1 : 0, db.reconfigured ? 1 : 0);
+    s += line;
     if (static_cast<int>(s.size()) + 1 > cap) return -1;
     std::memcpy(out, s.c_str(), s.size() + 1);
     return static_cast<int>(s.size());

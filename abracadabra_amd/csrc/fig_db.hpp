@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -91,6 +92,11 @@ public:
     std::vector<uint32_t> pty_changed;                // SIds whose PTy changed since the owner last looked
     bool switching_changed = false;
     int fibs_seen = 0;
+    // multiplex reconfiguration (EN 300 401 §6.5): FIGs of the multiplex configuration sent with C/N = 1 describe the
+    // NEXT configuration; FIG 0/0 announces the change and the CIF count at which it takes effect
+    std::shared_ptr<Database> next;
+    bool change_pending = false, reconfigured = false;
+    int occurrence = -1;
 
     void clear() { *this = Database(); }
 
@@ -130,16 +136,30 @@ public:
 private:
     void fig0(const uint8_t *d, int len)
     {
-        const bool pd = (d[0] >> 5) & 1;
+        const bool pd = (d[0] >> 5) & 1, cn = d[0] >> 7;
         const int ext = d[0] & 0x1F;
         const uint8_t *p = d + 1;
         int n = len - 1;
+        if (cn && (ext == 1 || ext == 2 || ext == 3 || ext == 8 || ext == 14)) {   // part of the next multiplex configuration
+            if (!next) next = std::make_shared<Database>();
+            uint8_t tmp[32];
+            std::memcpy(tmp, d, static_cast<size_t>(len));
+            tmp[0] &= 0x7F;
+            next->fig0(tmp, len);
+            return;
+        }
         switch (ext) {
         case 0:
             if (n >= 4) {
                 ens.eid = (p[0] << 8) | p[1];
                 ens.alarm = (p[2] >> 5) & 1;
                 ens.cif_count = (p[2] & 0x1F) * 250 + p[3];
+                const bool change = (p[2] >> 6) != 0;
+                if (change && n >= 5) occurrence = p[4];
+                // the new configuration is valid from the CIF whose count (lower part) equals the occurrence value;
+                // a receiver that missed that FIB applies it when the announcement is withdrawn
+                if (next && ((change && p[3] == occurrence) || (!change && change_pending))) apply_next();
+                change_pending = change;
             }
             break;
         case 1:
@@ -337,6 +357,33 @@ private:
             break;
         default: break;
         }
+    }
+
+    void apply_next()
+    {
+        subch = next->subch;
+        packet = next->packet;
+        fec_scheme = next->fec_scheme;
+        std::map<uint32_t, Service> now;
+        for (auto &kv : next->services) {                 // organisation from the new configuration, service information (labels,
+            Service sv = kv.second;                       // programme type, announcements, user applications) carried over
+            auto old = services.find(kv.first);
+            if (old != services.end()) {
+                sv.label = old->second.label; sv.label_flag = old->second.label_flag;
+                sv.pty = old->second.pty; sv.pty_dynamic = old->second.pty_dynamic;
+                sv.asu = old->second.asu; sv.clusters = old->second.clusters;
+                for (auto &c : sv.comp)
+                    for (const auto &oc : old->second.comp)
+                        if (oc.tmid == c.tmid && oc.subch == c.subch && oc.scid == c.scid) {
+                            c.label = oc.label; c.label_flag = oc.label_flag; c.apps = oc.apps;
+                            if (!c.scids_known) { c.scids = oc.scids; c.scids_known = oc.scids_known; }
+                        }
+            }
+            now[kv.first] = sv;
+        }
+        services = now;
+        next.reset();
+        reconfigured = true;
     }
 
     static std::string label16(const uint8_t *c)

@@ -80,3 +80,33 @@ def test_malformed_figs_are_skipped():
            fib(fig0(18, [0x1A, 0x01, 0, 3, 31]))]                      # 31 clusters announced
     text = dump(bad)
     assert "packet" not in text and "switching" not in text
+
+
+def test_multiplex_reconfiguration_is_applied_at_its_cif_count():
+    """EN 300 401 §6.5: the next configuration travels with C/N = 1 and must not touch the current one until the CIF count
+    announced by FIG 0/0 (change flags + occurrence change) is reached; labels and other service information survive."""
+    sid = 0x1A01
+
+    def fig00(cif, change=0, occ=None):
+        b = [0x10, 0xAB, (change << 6) | (cif // 250), cif % 250] + ([occ] if occ is not None else [])
+        return fig0(0, b)
+
+    def mci(cn, start, size):
+        sub = bytes([len([0] * 4) + 1, (cn << 7) | 1, 0x00 | (start >> 8), start & 0xFF, 0x80 | (2 << 2) | (size >> 8), size & 0xFF])   # SubCh 0, EEP 3-A
+        srv = bytes([6, (cn << 7) | 2, sid >> 8, sid & 0xFF, 0x01, 0x3F, 0x02])
+        return sub, srv
+
+    label = bytes([0x20 | 21, 0x01, sid >> 8, sid & 0xFF]) + b"STAYS THE SAME  " + bytes([0xFF, 0x00])
+    cur = mci(0, 0, 48)
+    nxt = mci(1, 100, 72)                                            # the sub-channel moves and grows: 64 -> 96 kbit/s
+    before = [fib(fig00(100), *cur), fib(label)]
+    during = [fib(fig00(120, change=1, occ=130), *cur), fib(*nxt)]
+    at = [fib(fig00(130, change=1, occ=130), *mci(0, 100, 72))]
+    text = dump(before + during)
+    assert "subch id=0 start=0 size=48" in text and "reconfiguration pending=1 next=1 applied=0" in text
+    text = dump(before + during + at)
+    assert "subch id=0 start=100 size=72 opt=0 level=3 kbps=96" in text and "label='STAYS THE SAME  '" in text
+    assert "reconfiguration pending=1 next=0 applied=1" in text
+    # a receiver that missed the FIB of the change itself applies it when the announcement is withdrawn
+    text = dump(before + during + [fib(fig00(140), *mci(0, 100, 72))])
+    assert "start=100 size=72" in text and "applied=1" in text
