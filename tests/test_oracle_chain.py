@@ -119,3 +119,19 @@ def test_tii_in_null_symbol_is_detected():
         power = s.null_spectrum()                     # keep the array alive across the call
         n = L.dabsdr_amd_tii_detect(power.ctypes.data, 4.0, ids.ctypes.data, 24)
         assert (n, tuple(ids[:2 * n])) == ((1, tii) if tii else (0, ()))
+
+
+def test_tii_pattern_numbering_matches_the_published_table():
+    """EN 300 401 table 42 (the host application carries the same table, reference src/dabtables.cpp:2338-2409, and turns
+    main id p into carrier-pair positions 24 b + c): pattern 0 = 00001111 -> b 4..7, pattern 1 = 00010111 -> b 3,5,6,7,
+    pattern 9 = 00110011 -> b 2,3,6,7, pattern 69 = 11110000 -> b 0..3.  Checked on the transmitted null symbol."""
+    for p, bs in ((0, {4, 5, 6, 7}), (1, {3, 5, 6, 7}), (9, {2, 3, 6, 7}), (69, {0, 1, 2, 3})):
+        c = 5
+        iq, _, _ = ob.tx_generate(seed=6, n_frames=4, subch=ob.subch_layout(1, 64), delay=0, snr_db=60.0, tii=(p, c))
+        s = ob.Stream()
+        s.push(iq)
+        assert s.process(2)["fib_ok"].all()
+        power = s.null_spectrum()
+        folded = np.array([sum(power[(base + j) & 2047] for base in (-768, -384, 1, 385)) for j in range(384)])
+        pair = np.array([folded[2 * c + 48 * b] + folded[2 * c + 48 * b + 1] for b in range(8)])
+        assert {int(b) for b in np.argsort(pair)[-4:]} == bs and np.sort(pair)[4] > 100 * np.sort(pair)[3]
