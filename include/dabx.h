@@ -16,6 +16,7 @@
 #ifndef DABX_H
 #define DABX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -62,3 +62,22 @@ def test_fig_database_reads_transmitted_fibs():
     assert "subch id=2 start=100 size=58 opt=0 level=2 kbps=64" in text          # UEP index 17 via the short form
     assert "service sid=1A01 label='SERVICE 00      ' ncomp=1 [tmid=0 ty=63 subch=0 ps=1]" in text
     assert "service sid=1A03 label='SERVICE 02      ' ncomp=1 [tmid=0 ty=0 subch=2 ps=1]" in text
+
+
+def test_public_headers_compile_as_plain_c(tmp_path):
+    """include/*.h are the boundary a C or cgo/JNI binding would include: they must stand alone under a C compiler,
+    and the record layouts the Python bindings mirror must have the documented sizes"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include")
+    src = tmp_path / "h.c"
+    src.write_text('#include "dabx.h"\n#include "dabsdr_amd.h"\n'
+                   '_Static_assert(sizeof(dabx_superframe_t) == 32, "super frame record");\n'
+                   '_Static_assert(sizeof(dabx_sync_rec_t) == 64, "sync record");\n'
+                   '_Static_assert(sizeof(dabsdrNtfPeriodic_t) == 32, "periodic notification (radiocontrol.cpp:2407)");\n'
+                   'int main(void) { return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "h.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
