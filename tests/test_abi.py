@@ -81,3 +81,16 @@ def test_public_headers_compile_as_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "h.o")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_c_example_builds_against_the_library(tmp_path):
+    """examples/decode_rawfiles.c is the batch ABI used from plain C: it must compile and link"""
+    import shutil
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    if not shutil.which("gcc") or not os.path.exists(os.path.join(root, "abracadabra_amd", "libdabsdr_amd.so")):
+        pytest.skip("gcc or the built library missing")
+    r = subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-o", str(tmp_path / "ex"),
+                        os.path.join(root, "examples", "decode_rawfiles.c"), "-L", os.path.join(root, "abracadabra_amd"), "-l:libdabsdr_amd.so"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
