@@ -337,6 +337,7 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
 void dabx_destroy(dabx_ctx *c)
 {
     if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
@@ -356,6 +357,7 @@ int dabx_set_subchannels(dabx_ctx *c, int s, int n, const dabx_subch_t *sub)
 {
     if (!valid_stream(c, s) || n < 0 || n > DABX_MAX_SUBCH || (n && !sub)) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
     std::vector<dabx::Profile> prof(n);
     std::vector<DevSub> ds(64, DevSub{});
@@ -384,6 +386,7 @@ int dabx_push(dabx_ctx *c, int s, const void *src, int64_t n, int kind)
 {
     if (!valid_stream(c, s) || n < 0 || (n && !src) || kind < DABX_SRC_HOST || kind > DABX_SRC_PINNED) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     auto &sh = c->streams[s];
     const int64_t len = c->cfg.ring_samples;
     // samples older than (pos - one frame) are no longer needed by any kernel; while a step is in flight
@@ -413,6 +416,7 @@ int dabx_push_all(dabx_ctx *c, const void *src, size_t stride, int64_t n, int ki
     bool lockstep = true;
     {
         std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
         for (int s = 0; s < S; ++s) {
             const auto &sh = c->streams[s];
             lockstep = lockstep && sh.wr == c->streams[0].wr;
@@ -463,6 +467,7 @@ int dabx_set_write_pos(dabx_ctx *c, int s, int64_t wr)
 {
     if (!valid_stream(c, s) || wr < 0) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     c->streams[s].wr = wr;
     return DABX_OK;
 }
@@ -471,6 +476,7 @@ int dabx_frames_available(dabx_ctx *c)
 {
     if (!c) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     int best = c->cfg.max_frames;
     for (const auto &sh : c->streams) {
         int n = 0;
@@ -484,6 +490,7 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
 {
     if (!c || n_frames < 1 || n_frames > c->cfg.max_frames) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
     for (const auto &sh : c->streams) {
         if (samples_needed(sh, n_frames) > sh.wr) return DABX_E_UNDERRUN;
@@ -534,6 +541,7 @@ int dabx_wait(dabx_ctx *c)
 {
     if (!c) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (!c->pending) return DABX_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int s = 0; s < c->cfg.n_streams; ++s) c->streams[s].st = c->h_state[s];
@@ -557,6 +565,7 @@ int dabx_process(dabx_ctx *c, int n_frames)
 #define GETTER_PROLOGUE                                            \
     if (!valid_stream(c, s)) return DABX_E_ARG;                    \
     std::lock_guard<std::mutex> lk(c->mu);                         \
+    (void)hipSetDevice(c->cfg.device);                             \
     if (c->pending) return DABX_E_ARG;                             \
     const size_t F = c->cfg.max_frames, n = c->last_frames;        \
     (void)F; (void)n;
@@ -627,6 +636,7 @@ int dabx_get_fib_counts(dabx_ctx *c, int64_t *ok, int64_t *bad)
 {
     if (!c) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
     const size_t S = c->cfg.n_streams, F = c->cfg.max_frames, n = c->last_frames;
     std::vector<uint8_t> h(S * F * 12);
@@ -643,6 +653,7 @@ int dabx_fft2048(dabx_ctx *c, const float *in, float *out, int n_vec)
 {
     if (!c || !in || !out || n_vec < 1) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     float2 *d_in = nullptr, *d_out = nullptr;
     const size_t bytes = static_cast<size_t>(n_vec) * 2048 * sizeof(float2);
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_in), bytes));
@@ -660,6 +671,7 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
 {
     if (!c || !soft || !out || n_cw < 1) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     dabx::Profile p = dabx::fic_profile();
     if (kind != 0 && !dabx::any_profile(option, level, kbps, p)) return DABX_E_PROFILE;
     const auto info = dabx::step_info(p);
@@ -685,6 +697,7 @@ int dabx_enable_spectrum(dabx_ctx *c, int mask)
 {
     if (!c) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
     const size_t bytes = static_cast<size_t>(c->cfg.n_streams) * 2048 * sizeof(float);
     float **bufs[2] = {&c->d_spectrum, &c->d_null_spectrum};
@@ -721,6 +734,7 @@ int dabx_set_dabplus(dabx_ctx *c, int s, uint64_t mask)
 {
     if (!valid_stream(c, s)) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
     auto &sh = c->streams[s];
     if (sh.sub.size() < 64 && (mask >> sh.sub.size())) return DABX_E_ARG;
