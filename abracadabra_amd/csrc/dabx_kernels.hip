@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             for (int e = 0; e < 8; ++e)
                 if (nidx[e] >= 0) {
                     float a = rintf(y[e].r * gsc), b = rintf(y[e].i * gsc);
-                    a = fminf(fmaxf(a, -127.0f), 127.0f); b = fminf(fmaxf(b, -127.0f), 127.0f);
+                    a = __builtin_amdgcn_fmed3f(a, -127.0f, 127.0f); b = __builtin_amdgcn_fmed3f(b, -127.0f, 127.0f);   // clamp in one instruction
                     const int n0 = nidx[e], n1 = nidx[e] + NCAR;
                     if (l <= 3) { soft[n0] = (int8_t)a; soft[n1] = (int8_t)b; }
                     else {                     // MSC: stage residue-major (3072 = 16 * 192, so (n & 15) is the residue)
