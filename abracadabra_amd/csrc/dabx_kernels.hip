@@ -496,9 +496,16 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     __shared__ float2 twl[TWL];
     cf twa[7];
     load_twiddles_lds(twa, twl, T.W, t);
-    __shared__ int16_t nidx_l[TU];                       // frequency de-interleaver target of each FFT output position (-1: unused bin)
+    // where the soft bits of each FFT output position go in the staging buffer (-1: unused bin): the frequency
+    // de-interleaver index n itself for FIC symbols ([0]), its residue-major place (n & 15) * 192 + (n >> 4) for MSC
+    // symbols ([1]); the imaginary part sits 1536 resp. 96 bytes further (1536 = 16 * 96)
+    __shared__ int16_t dst_l[2][TU];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) nidx_l[8 * t + e] = T.n_of_bin[T.bin_of_pos[8 * t + e]];
+    for (int e = 0; e < 8; ++e) {
+        const int n = T.n_of_bin[T.bin_of_pos[8 * t + e]];
+        dst_l[0][8 * t + e] = static_cast<int16_t>(n);
+        dst_l[1][8 * t + e] = static_cast<int16_t>(n < 0 ? -1 : (n & 15) * (SYMBITS / 16) + (n >> 4));
+    }
 
     const int l_first = g * DEMOD_GSYMS;                 // first symbol to demap (0 = PRS: reference only)
     const int l_ref = l_first == 0 ? 0 : l_first - 1;    // symbol whose spectrum seeds the differential
@@ -514,8 +521,10 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             cf y[8];
             int nidx[8];
             float acc = 0.0f;
+            const int16_t *tab = dst_l[l <= 3 ? 0 : 1];
+            const int imoff = l <= 3 ? NCAR : NCAR / 16;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) nidx[e] = nidx_l[8 * t + e];
+            for (int e = 0; e < 8; ++e) nidx[e] = tab[8 * t + e];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 y[e] = cmulc(v[e], prev[e]);
@@ -528,12 +537,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
                 if (nidx[e] >= 0) {
                     float a = rintf(y[e].r * gsc), b = rintf(y[e].i * gsc);
                     a = __builtin_amdgcn_fmed3f(a, -127.0f, 127.0f); b = __builtin_amdgcn_fmed3f(b, -127.0f, 127.0f);   // clamp in one instruction
-                    const int n0 = nidx[e], n1 = nidx[e] + NCAR;
-                    if (l <= 3) { soft[n0] = (int8_t)a; soft[n1] = (int8_t)b; }
-                    else {                     // MSC: stage residue-major (3072 = 16 * 192, so (n & 15) is the residue)
-                        soft[(n0 & 15) * (SYMBITS / 16) + (n0 >> 4)] = (int8_t)a;
-                        soft[(n1 & 15) * (SYMBITS / 16) + (n1 >> 4)] = (int8_t)b;
-                    }
+                    soft[nidx[e]] = (int8_t)a;
+                    soft[nidx[e] + imoff] = (int8_t)b;
                 }
             __syncthreads();
             if (l <= 3) {
