@@ -9,13 +9,21 @@ configs[3]) x `--frames` transmission frames each.  Every stream is a seeded, pe
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; ensembles are
-sharded one-per-stream across ranks with no data-path collective (weak scaling); RCCL
-carries only the max-over-ranks time and the FIB counters.
+N > 1: one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) the process IS a
+rank; started plainly with --gpus N > 1 it launches `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child BEFORE anything touches the GPU and exits with the
+child's code.  Ensembles are sharded one-per-stream across ranks (global stream g lives on rank
+g // streams_per_gpu) with no data-path collective (weak scaling); RCCL carries only the
+max-over-ranks time and the FIB / payload counters.
+
+The rank body (`run_rank`) is engine-agnostic: tests/test_multirank.py runs exactly this code
+on two gloo CPU ranks with a CPU checker engine, the GPU engine below is the product path.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -29,19 +37,21 @@ if ROOT not in sys.path:
 FRAME_S = 0.096
 TF = 196608
 SYMS_PER_FRAME = 76
-# algorithmic HBM bytes per ensemble-frame (SURVEY.md §8d, u8 input, int8 soft bits)
+# algorithmic HBM bytes per ensemble-frame (SURVEY.md §8d, u8 input, int8 soft bits; DESIGN.md §5)
 BYTES_CHAIN = 393216 + 230400 + 230400 + 14208          # IQ read + soft write + soft read + decoded bytes
-BYTES_VITERBI = 230400 + 14208                          # dominant kernel: soft-bit read + decoded bytes
-BYTES_DEMOD = 387904 + 230400                           # k_demod: IQ of the 76 data/reference symbols + soft-bit write
-ACS_PER_FRAME = (4 * 774 + 4 * 18 * 1542) * 64          # trellis steps x 64 states, 18 x 48 CU EEP 3-A
+BYTES_VITERBI = 230400 + 14208                          # k_viterbi: soft-bit read + decoded bytes
+BYTES_DEMOD = 80 * 2048 * 2 + 230400                    # k_demod: 4 groups x 20 FFT windows of 2048 u8 IQ pairs (the 504-sample
+                                                        # guard is never read; 4 of the 80 windows are re-read seeds) + soft-bit write
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9               # 256 CU x 4 SIMD-32 x 2.4 GHz
+N_SIMD = 256 * 4                                        # 256 CU x 4 SIMD-32
+CLOCK_HZ = 2.4e9
+VALU_CYCLES_PER_WAVE_INST = 2                           # wave64 on a SIMD-32 (MI355X_MICROARCH.md, Wave scheduling)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=256, help="ensembles per GPU")
     ap.add_argument("--frames", type=int, default=8, help="transmission frames per stream per step")
@@ -55,13 +65,45 @@ def parse_args():
                          "(period 20 frames = 16 super frames per sub-channel; not the headline workload)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: put every rank on this GPU")
-    ap.add_argument("--cpu-frames", type=int, default=208)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each cpu_baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline (0 = the cores this process may use, at most 16)")
+    return ap.parse_args(argv)
 
 
-def make_stream(args, rank, s, sub):
-    from oracle import binding as ob          # synthetic transmitter lives with the test infrastructure
-    gid = rank * args.streams + s
+# ------------------------------------------------------------------------------------------- launching N ranks
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_cmd(n, port, script, argv):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+
+
+def relaunch_if_needed(args, argv, script):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks as a child process (no GPU, HIP or
+    torch.cuda call has happened in this process) and return its exit code; None when this process is a rank."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the flag and the launcher disagree")
+        return None
+    if args.gpus <= 1:
+        return None
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(launch_cmd(args.gpus, free_port(), script, argv), env=env)
+
+
+# ------------------------------------------------------------------------------------------------ the workload
+def stream_ids(rank, streams_per_rank):
+    """global ensemble ids decoded by `rank` (one contiguous block per GPU)"""
+    return list(range(rank * streams_per_rank, (rank + 1) * streams_per_rank))
+
+
+def make_stream(args, gid, sub):
+    from oracle import binding as ob          # the synthetic transmitter lives with the test infrastructure
     rng = np.random.default_rng(1000 + gid)
     payload = None
     if args.dabplus:                           # 4 P logical frames = whole super frames, so the periodic signal stays in sync
@@ -74,106 +116,51 @@ def make_stream(args, rank, s, sub):
     return iq, fib, msc, shift
 
 
-def measured_traffic(S, F, kernel="k_viterbi"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py from the same bench
-    command under rocprofv3); None when no profile matches this workload."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    for f in reversed(files):
-        try:
-            t = json.load(open(f))
-        except Exception:
-            continue
-        if t.get("workload") == {"streams": S, "frames_per_step": F}:
-            for k, v in t["kernels"].items():
-                if kernel in k:
-                    return v["hbm_bytes_per_launch"], os.path.basename(f)
-    return None, None
+class GpuEngine:
+    """The product path: abracadabra_amd (libdabsdr_amd.so) through its C ABI."""
+    uses_gpu = True
+
+    def __init__(self, args, dev, sub):
+        import abracadabra_amd as aa
+        self.aa, self.args, self.dev, self.sub = aa, args, dev, sub
+        self.ctx = aa.Context(n_streams=args.streams, fmt=0, ring_frames=args.period, max_frames=args.frames, device=dev)
+        self.ctx.enable_timing(True)
+
+    def load(self, s, iq):
+        self.ctx.set_subchannels(s, self.sub)
+        self.ctx.push(s, iq)                   # fills the ring exactly once: the signal is periodic
+        self.ctx.set_write_pos(s, 1 << 62)     # resident periodic ring: never underruns
+        if self.args.dabplus:
+            self.ctx.set_dabplus(s, (1 << len(self.sub)) - 1)
+
+    def step(self):
+        """one decode step over every stream; returns [sync, fft_demap, viterbi, post, all] in ms (HIP events on the context's stream)"""
+        self.ctx.process(self.args.frames)
+        return self.ctx.last_timing()
+
+    def fib_counts(self):
+        return self.ctx.fib_counts()
+
+    def fib(self, s):
+        return self.ctx.fib(s)
+
+    def msc(self, s):
+        return self.ctx.msc(s)
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
 
 
-def cpu_baseline(args, sub):
-    """Oracle (scalar CPU port of the same chain) timed on one host core over a bounded sample."""
-    from oracle import binding as ob
-    n = args.cpu_frames
-    iq, _, _ = ob.tx_generate(seed=99, n_frames=n + 2, subch=sub, delay=777, snr_db=args.snr, cfo_hz=1234.0)
-    orc = ob.Stream(subch=sub, ring_len=(n + 4) * TF, ti_slots=64)
-    orc.push(iq)
-    orc.process(4, want_soft=False)            # acquisition outside the timed sample
-    done, t0 = 0, time.perf_counter()
-    while done + 4 <= n - 4:
-        if orc.process(4, want_soft=False)["rc"] != 4:
-            break
-        done += 4
-    dt = time.perf_counter() - t0
-    return {"value": round(done * FRAME_S / dt, 4), "unit": "x real-time (ensemble-seconds per second)", "cores": 1,
-            "kind": "port", "sample": f"1 ensemble x {done} frames, full FIC + 18 x 48 CU MSC, oracle/dab_rx.c, {dt:.1f} s"}
-
-
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
-    dev = args.force_device if args.force_device >= 0 else local_rank
-    torch.cuda.set_device(dev)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(args.backend)
-
-    import abracadabra_amd as aa
-    from oracle import binding as ob
-    sub = ob.subch_layout(args.nsub, 64)        # default: all 864 CU = 18 x 48 CU, EEP 3-A, 64 kbit/s
-    if args.dabplus:
-        args.period = 20
-    S, F, P = args.streams, args.frames, args.period
-    assert P % 4 == 0 and P >= F + 2
-
-    t_gen = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
-        streams = list(ex.map(lambda s: make_stream(args, rank, s, sub), range(S)))
-    t_gen = time.perf_counter() - t_gen
-
-    ctx = aa.Context(n_streams=S, fmt=0, ring_frames=P, max_frames=F, device=dev)
-    for s, (iq, _, _, _) in enumerate(streams):
-        ctx.set_subchannels(s, sub)
-        ctx.push(s, iq)                          # fills the ring exactly once: the signal is periodic
-        ctx.set_write_pos(s, 1 << 62)            # resident periodic ring: never underruns
-        if args.dabplus:
-            ctx.set_dabplus(s, (1 << len(sub)) - 1)
-    ctx.enable_timing(True)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        ctx.process(F)
-    barrier()
-    t0 = time.perf_counter()
-    phase_ms = np.zeros(5)
-    for _ in range(args.steps):
-        ctx.process(F)
-        phase_ms += np.array(ctx.last_timing())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ok, bad = ctx.fib_counts()
-
-    # ---- correctness of what was just timed (outside the timed region): FIB CRCs and,
-    # for a few streams, decoded FIBs / MSC bytes against the transmitted payload
-    mism = 0
-    checked = 0
-    for s in range(0, S, max(1, S // 8)):
+def verify(engine, streams, S, F, P):
+    """decoded FIBs / MSC bytes of the last step against the transmitted payload (periodic signal: set membership),
+    every stream"""
+    mism = checked = 0
+    for s in range(S):
         _, fib_tx, msc_tx, _ = streams[s]
-        gf, gok = ctx.fib(s)
-        gm, gv = ctx.msc(s)
+        gf, gok = engine.fib(s)
+        gm, gv = engine.msc(s)
         fib_set = {fib_tx[f].tobytes() for f in range(P)}
         for f in range(F):
             checked += 1
@@ -184,99 +171,218 @@ def main():
                 if gv[f, c]:
                     checked += 1
                     mism += (gm[f, c].tobytes() not in msc_set)
+    return checked, mism
+
+
+def reduce_over_ranks(dist, world, device, elapsed, counters):
+    """max-over-ranks time and summed counters: the only collective of the run (<= 64 bytes)"""
+    if world == 1:
+        return elapsed, [int(c) for c in counters]
+    import torch
+    t = torch.tensor([elapsed] + [float(c) for c in counters], dtype=torch.float64, device=device)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(tmax[0]), [int(round(float(x))) for x in t[1:]]
+
+
+def profile_counters(S, F, kernel="k_viterbi"):
+    """Per-launch PMC figures of `kernel` from the committed rocprofv3 passes of this workload
+    (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py from the same bench command under
+    rocprofv3): HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM) and SQ_INSTS_VALU."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == {"streams": S, "frames_per_step": F}:
+            for k, v in t["kernels"].items():
+                if kernel in k:
+                    return v.get("hbm_bytes_per_launch"), v.get("insts_valu_per_launch"), os.path.basename(f)
+    return None, None, None
+
+
+def cpu_baseline(args):
+    """oracle/cpu_bench: the scalar CPU restatement of the same chain, one ensemble per thread, no Python in the loop;
+    full FIC+MSC and FIC-only legs."""
+    exe = os.path.join(ROOT, "oracle", "cpu_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "cpu_bench"])
+    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+
+    def leg(th, nsub, seconds):
+        out = subprocess.run([exe, str(th), str(seconds), str(nsub), str(args.snr)], capture_output=True, text=True, timeout=600)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    full = leg(threads, args.nsub, args.cpu_seconds)
+    one = leg(1, args.nsub, min(4.0, args.cpu_seconds))
+    fic = leg(threads, 0, min(4.0, args.cpu_seconds))
+    return {"value": full["x_realtime"], "unit": "x real-time (ensemble-seconds per second), all threads together", "cores": threads, "kind": "port",
+            "per_core": full["x_realtime_per_thread"], "single_thread_alone": one["x_realtime"],
+            "fic_only": {"value": fic["x_realtime"], "per_core": fic["x_realtime_per_thread"], "cores": threads},
+            "sample": f"oracle/cpu_bench (C, pthreads): {threads} ensembles x {full['frames'] // threads} frames in {full['seconds']:.1f} s, full FIC + "
+                      f"{args.nsub} x 48 CU MSC; FIC-only leg {fic['frames'] // threads} frames per thread in {fic['seconds']:.1f} s",
+            "note": "a port (our CPU restatement, scalar C -O3), not the reference's closed libdabsdr; SURVEY.md §6 measured that binary at "
+                    "~190 x/core FIC-only and estimated ~12 x/core with the whole MSC decoded"}
+
+
+def pcie_leg(args, dev, streams, sub):
+    """The same step fed through the host boundary, reported beside `value`, never as `value`: (a) dabx_push from
+    pageable numpy arrays, synchronous; (b) from page-locked buffers the "file reader" has already filled, queued on the
+    copy stream while the previous step decodes (DABX_SRC_PINNED + dabx_process_async)."""
+    import torch
+    import abracadabra_amd as aa
+    S, F, P = args.streams, args.frames, args.period
+    per = P * TF
+    k_steps = 5
+    first = (F + 1) * TF + 4096
+
+    def run(pinned):
+        c2 = aa.Context(n_streams=S, fmt=0, ring_frames=2 * F + 4, max_frames=F, device=dev)   # room for the step in flight + the next
+        if pinned:
+            stage = c2.alloc_pinned(S * per * 2)
+            for s_, (iq, _, _, _) in enumerate(streams):
+                stage[s_ * per * 2:(s_ + 1) * per * 2] = iq
+        pos = [0] * S
+
+        def push(s_, n):                  # next n samples of the periodic stream s_
+            a = pos[s_] % per
+            for a0, n0 in ((a, min(n, per - a)), (0, n - min(n, per - a))):
+                if n0 <= 0:
+                    continue
+                c2.push(s_, streams[s_][0][2 * a0:2 * (a0 + n0)])
+            pos[s_] += n
+
+        def push_step(n):                 # every stream advances by n samples
+            if not pinned:
+                for s_ in range(S):
+                    push(s_, n)
+                return
+            a = pos[0] % per              # lock step: one strided copy (two when the period wraps)
+            for a0, n0 in ((a, min(n, per - a)), (0, n - min(n, per - a))):
+                if n0 > 0:
+                    c2.push_all(stage.ctypes.data + a0 * 2, per * 2, n0, kind=2)
+            for s_ in range(S):
+                pos[s_] += n
+
+        for s_ in range(S):
+            c2.set_subchannels(s_, sub)
+        push_step(first)
+        c2.process(F)                     # acquisition, untimed
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        push_step(F * TF)
+        for k in range(k_steps):
+            c2.process_async(F)
+            if k + 1 < k_steps:
+                push_step(F * TF)         # the next step's samples travel while this one decodes
+            c2.wait()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        _, bad2 = c2.fib_counts()
+        if pinned:
+            c2.free_pinned(stage)
+        c2.close()
+        return {"value": round(S * F * k_steps * FRAME_S / dt, 1), "ms_per_step": round(dt / k_steps * 1e3, 2), "fib_crc_bad": bad2}
+
+    return {"unit": "x real-time", "host_bytes_per_step": S * F * TF * 2,
+            "pageable_synchronous": run(False), "pinned_overlapped": run(True)}
+
+
+# ---------------------------------------------------------------------------------------------------- one rank
+def run_rank(args, engine_factory=None):
+    """Body of one rank (the whole run when N = 1).  Returns the process exit code."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    gpu = engine_factory is None or getattr(engine_factory, "uses_gpu", False)
+    dist = None
+    dev = args.force_device if args.force_device >= 0 else local_rank
+    torch = None
+    if gpu or world > 1:
+        import torch
+    if gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
+        torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
+    red_device = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
+
+    from oracle import binding as ob             # signal synthesis + the cpu_baseline leg only
+    sub = ob.subch_layout(args.nsub, 64)         # default: all 864 CU = 18 x 48 CU, EEP 3-A, 64 kbit/s
+    if args.dabplus:
+        args.period = 20
+    S, F, P = args.streams, args.frames, args.period
+    assert P % 4 == 0 and P >= F + 2
+
+    gids = stream_ids(rank, S)
+    t_gen = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as ex:
+        streams = list(ex.map(lambda g: make_stream(args, g, sub), gids))
+    t_gen = time.perf_counter() - t_gen
+
+    engine = (engine_factory or GpuEngine)(args, dev, sub)
+    for s, (iq, _, _, _) in enumerate(streams):
+        engine.load(s, iq)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if gpu:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.step()
+    barrier()
+    t0 = time.perf_counter()
+    phase_ms = np.zeros(5)
+    for _ in range(args.steps):
+        phase_ms += np.array(engine.step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ok, bad = engine.fib_counts()
+
+    # ---- correctness of what was just timed (outside the timed region)
+    checked, mism = verify(engine, streams, S, F, P)
 
     dabplus = None
     if args.dabplus:                             # what k_superframe made of the sub-channels of a few streams
         tot = {}
         for s in range(0, S, max(1, S // 8)):
             for k in range(len(sub)):
-                for key, v in ctx.superframe_stats(s, k).items():
+                for key, v in engine.ctx.superframe_stats(s, k).items():
                     tot[key] = tot.get(key, 0) + v
         dabplus = {"stats_of_sampled_subchannels": tot, "post_viterbi_ms_per_step": round(float(phase_ms[3]) / args.steps, 3),
                    "superframes_per_step": S * len(sub) * 4 * F // 5}
 
-    # ---- the same step fed through the host boundary, reported beside `value`, never as `value` (the inputs of
-    # the timed region above are resident): (a) dabx_push from pageable numpy arrays, synchronous; (b) from
-    # page-locked buffers the "file reader" has already filled, queued on the copy stream while the previous
-    # step decodes (DABX_SRC_PINNED + dabx_process_async)
     pcie = None
-    if world == 1 and not args.no_pcie:
-        ctx.close()
-        ctx = None
-        per = P * TF
-        k_steps = 5
-        first = (F + 1) * TF + 4096
+    if gpu and world == 1 and not args.no_pcie:
+        engine.close()
+        pcie = pcie_leg(args, dev, streams, sub)
 
-        def run(pinned):
-            c2 = aa.Context(n_streams=S, fmt=0, ring_frames=2 * F + 4, max_frames=F, device=dev)   # room for the step in flight + the next
-            if pinned:
-                stage = c2.alloc_pinned(S * per * 2)
-                for s_, (iq, _, _, _) in enumerate(streams):
-                    stage[s_ * per * 2:(s_ + 1) * per * 2] = iq
-            pos = [0] * S
+    elapsed, (ok, bad, mism, checked, n_streams) = reduce_over_ranks(dist, world, red_device, elapsed, [ok, bad, mism, checked, S])
 
-            def push(s_, n):                  # next n samples of the periodic stream s_
-                a = pos[s_] % per
-                for a0, n0 in ((a, min(n, per - a)), (0, n - min(n, per - a))):
-                    if n0 <= 0:
-                        continue
-                    if pinned:
-                        c2.push_pinned(s_, stage.ctypes.data + (s_ * per + a0) * 2, n0)
-                    else:
-                        c2.push(s_, streams[s_][0][2 * a0:2 * (a0 + n0)])
-                pos[s_] += n
-
-            def push_step(n):                 # every stream advances by n samples
-                if not pinned:
-                    for s_ in range(S):
-                        push(s_, n)
-                    return
-                a = pos[0] % per              # lock step: one strided copy (two when the period wraps)
-                for a0, n0 in ((a, min(n, per - a)), (0, n - min(n, per - a))):
-                    if n0 > 0:
-                        c2.push_all(stage.ctypes.data + a0 * 2, per * 2, n0, kind=2)
-                for s_ in range(S):
-                    pos[s_] += n
-
-            for s_ in range(S):
-                c2.set_subchannels(s_, sub)
-            push_step(first)
-            c2.process(F)                     # acquisition, untimed
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            push_step(F * TF)
-            for k in range(k_steps):
-                c2.process_async(F)
-                if k + 1 < k_steps:
-                    push_step(F * TF)         # the next step's samples travel while this one decodes
-                c2.wait()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            _, bad2 = c2.fib_counts()
-            if pinned:
-                c2.free_pinned(stage)
-            c2.close()
-            return {"value": round(S * F * k_steps * FRAME_S / dt, 1), "ms_per_step": round(dt / k_steps * 1e3, 2), "fib_crc_bad": bad2}
-
-        pcie = {"unit": "x real-time", "host_bytes_per_step": S * F * TF * 2,
-                "pageable_synchronous": run(False), "pinned_overlapped": run(True)}
-
-    t = torch.tensor([elapsed, float(ok), float(bad), float(mism)], dtype=torch.float64,
-                     device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        ok, bad, mism = int(t[1]), int(t[2]), int(t[3])
-
+    rc = 0
     if rank == 0:
-        frames_total = world * S * F * args.steps
+        frames_total = n_streams * F * args.steps
         value = frames_total * FRAME_S / elapsed
         vit_ms = phase_ms[2] / args.steps
-        achieved = S * F * BYTES_VITERBI / (vit_ms * 1e-3) / 1e9
-        acs_rate = S * F * (4 * 774 + 4 * args.nsub * 1542) * 64 / (vit_ms * 1e-3)
-        traffic, traffic_src = measured_traffic(S, F) if args.nsub == 18 else (None, None)
+        dem_ms = phase_ms[1] / args.steps
+        steps_per_frame = 4 * 774 + 4 * args.nsub * 1542
+        achieved = S * F * BYTES_VITERBI / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
+        acs_rate = S * F * steps_per_frame * 64 / (vit_ms * 1e-3) if vit_ms > 0 else 0.0
+        traffic, insts_valu, prof_src = profile_counters(S, F) if args.nsub == 18 else (None, None, None)
+        d_traffic, d_insts, _ = profile_counters(S, F, "k_demod") if args.nsub == 18 else (None, None, None)
+
+        def issue_frac(insts, ms):                # wave-instructions x 2 cycles over the SIMD-cycles of the launch
+            return round(insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 4) if insts and ms > 0 else None
+
         out = {
             "metric": "DAB Mode-I ensembles decoded x real-time per GPU (2048-FFT + de-interleave + Viterbi, full FIC+MSC)",
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -287,22 +393,23 @@ def main():
                        "parallelism": f"{world} x independent streams, no data-path collective"},
             "msym_per_s": round(value / FRAME_S * SYMS_PER_FRAME / 1e6, 3),
             "x_realtime_per_gpu": round(value / world, 1),
-            "fib_crc_ok": ok, "fib_crc_bad": bad, "payload_checked": checked * world if world > 1 else checked, "payload_mismatch": mism,
-            "kernel_ms_per_step": {"sync": round(phase_ms[0] / args.steps, 3), "fft_demap": round(phase_ms[1] / args.steps, 3),
+            "fib_crc_ok": ok, "fib_crc_bad": bad, "payload_checked": checked, "payload_mismatch": mism,
+            "kernel_ms_per_step": {"sync": round(phase_ms[0] / args.steps, 3), "fft_demap": round(dem_ms, 3),
                                    "viterbi": round(vit_ms, 3), "crc_state": round(phase_ms[3] / args.steps, 3),
                                    "all": round(phase_ms[4] / args.steps, 3)},
             "roofline": {"kernel": "k_viterbi", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": S * F * BYTES_VITERBI,
-                         "note": "VALU-issue-bound kernel (DESIGN.md §7): HBM fraction is small by construction (SURVEY.md §0.8). "
-                                 "traffic = algorithmic bytes + the decision scratch (64 decision bits per trellis step, "
-                                 "written once and read once by the traceback: 2 x 8 B x steps)",
-                         "decision_scratch_bytes_per_launch": 2 * 8 * S * F * (4 * 774 + 4 * args.nsub * 1542),
+                         "traffic_source": prof_src, "algorithmic_bytes_per_launch": S * F * BYTES_VITERBI,
+                         "valu_issue_frac": issue_frac(insts_valu, vit_ms), "insts_valu_per_launch": insts_valu,
+                         "note": "the kernel is bound by VALU issue (DESIGN.md §7), not by HBM: `frac` is the HBM fraction the contract asks for and is "
+                                 "small by construction (SURVEY.md §0.8); `valu_issue_frac` = SQ_INSTS_VALU (committed PMC pass of this command) x 2 cycles "
+                                 "/ (1024 SIMDs x launch time measured here x 2.4 GHz) is the fraction of the binding resource",
                          "acs_per_s": round(acs_rate, 0),
                          "chain_algorithmic_GBps": round(value / world / FRAME_S * BYTES_CHAIN / 1e9, 2)},
             "other_kernels": {"k_demod": {"bound": "hbm", "algorithmic_bytes_per_launch": S * F * BYTES_DEMOD,
-                                          "achieved": round(S * F * BYTES_DEMOD / (phase_ms[1] / args.steps * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                          "frac": round(S * F * BYTES_DEMOD / (phase_ms[1] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                                          "achieved": round(S * F * BYTES_DEMOD / (dem_ms * 1e-3) / 1e9, 1) if dem_ms > 0 else 0.0, "unit": "GB/s",
+                                          "frac": round(S * F * BYTES_DEMOD / (dem_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dem_ms > 0 else 0.0,
+                                          "traffic": d_traffic, "valu_issue_frac": issue_frac(d_insts, dem_ms)}},
             "setup_s": {"synthesis": round(t_gen, 1)},
         }
         if args.dabplus:
@@ -310,13 +417,30 @@ def main():
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, sub)
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if ctx is not None:
-        ctx.close()
+        if bad or mism:
+            print(f"bench.py: FAILED correctness: fib_crc_bad={bad} payload_mismatch={mism}", file=sys.stderr)
+            rc = 1
+    engine.close()
     if world > 1:
+        # every rank leaves with the same verdict
+        import torch as _t
+        v = _t.tensor([float(rc)], dtype=_t.float64, device=red_device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        rc = int(v[0])
         dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None, engine_factory=None, script=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    rc = relaunch_if_needed(args, argv, script or os.path.abspath(__file__))
+    if rc is None:
+        rc = run_rank(args, engine_factory)
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -56,7 +56,9 @@ def lib():
 class TxCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("eid", C.c_int32), ("n_frames", C.c_int32), ("n_subch", C.c_int32),
                 ("delay", C.c_int32), ("loop", C.c_int32), ("fmt", C.c_int32), ("snr_db", C.c_double),
-                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64), ("payload_given", C.c_int32), ("tii_main", C.c_int32), ("tii_sub", C.c_int32), ("extra_figs", C.c_int32), ("packet_sub", C.c_int32)]
+                ("cfo_hz", C.c_double), ("rms", C.c_double), ("subch", (C.c_int32 * 4) * 64), ("payload_given", C.c_int32), ("tii_main", C.c_int32), ("tii_sub", C.c_int32), ("extra_figs", C.c_int32), ("packet_sub", C.c_int32),
+                ("sco_ppm", C.c_double), ("dc_i", C.c_double), ("dc_q", C.c_double), ("echo_db", C.c_double), ("echo_phase", C.c_double),
+                ("echo_delay", C.c_int32), ("eid2_from", C.c_int32)]          # = dab_tx_cfg_t (oracle/dab_tx.h)
 
 
 class Profile(C.Structure):
@@ -94,9 +96,11 @@ def subch_layout(n=18, kbps=64, option=0, level=3):
 
 
 def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0, snr_db=30.0, cfo_hz=0.0,
-                rms=28.0, payload=None, tii=None, extra_figs=False, packet_sub=0):
+                rms=28.0, payload=None, tii=None, extra_figs=False, packet_sub=0, sco_ppm=0.0, dc=(0.0, 0.0), echo=None, eid2_from=0):
     """Synthetic Mode-I signal.  Returns (iq, fib[n_frames,12,32], msc[n_frames*4, bytes_per_cif]).
-    payload: optional uint8 array [n_frames*4, bytes_per_cif] to transmit instead of random bytes."""
+    payload: optional uint8 array [n_frames*4, bytes_per_cif] to transmit instead of random bytes.
+    Channel impairments: sco_ppm (sampling clock offset of the recording), dc = (I, Q) offset in LSB,
+    echo = (delay_samples, attenuation_db, phase_rad) second path; eid2_from: frames from this index on carry EId + 1."""
     L = lib()
     cfg = TxCfg()
     cfg.seed, cfg.eid, cfg.n_frames, cfg.n_subch = seed, eid, n_frames, len(subch)
@@ -105,6 +109,9 @@ def tx_generate(seed=1, eid=0x1000, n_frames=2, subch=(), delay=0, loop=0, fmt=0
     cfg.tii_main, cfg.tii_sub = (tii if tii is not None else (-1, 0))
     cfg.extra_figs = 1 if extra_figs else 0
     cfg.packet_sub = int(packet_sub)
+    cfg.sco_ppm, cfg.dc_i, cfg.dc_q, cfg.eid2_from = float(sco_ppm), float(dc[0]), float(dc[1]), int(eid2_from)
+    if echo is not None:
+        cfg.echo_delay, cfg.echo_db, cfg.echo_phase = int(echo[0]), float(echo[1]), float(echo[2])
     for i, s in enumerate(subch):
         for j in range(4):
             cfg.subch[i][j] = int(s[j])
@@ -153,6 +160,11 @@ class Stream:
     def push(self, iq):
         iq = np.ascontiguousarray(iq)
         self.L.orx_push(self.h, iq.ctypes.data, iq.size // 2)
+
+    def set_write_pos(self, wr):
+        """wr = 1 << 62: resident periodic ring that never underruns (as dabx_set_write_pos)"""
+        self.L.orx_set_wr.argtypes = [C.c_void_p, C.c_int64]
+        self.L.orx_set_wr(self.h, wr)
 
     def spectrum(self):
         out = np.zeros(2048, dtype=np.float32)

@@ -240,9 +240,11 @@ typedef struct {                /* per-frame synchronisation record (same layout
     int64_t e_null, e_sig;      /* sample energy over 2048 samples of the null symbol / of the PRS */
 } orx_sync_t;
 
+static void vit_init(void);
 orx_t *orx_create(int fmt, int64_t ring_len, int ti_slots)
 {
     tables_init();
+    vit_init();
     orx_t *s = (orx_t *)calloc(1, sizeof *s);
     s->fmt = fmt; s->ring_len = ring_len;
     s->ring = (uint8_t *)calloc((size_t)ring_len, fmt ? 4 : 2);
@@ -285,6 +287,8 @@ void orx_push(orx_t *s, const void *iq, int64_t n)
     }
     s->wr += n;
 }
+/* resident periodic ring (benchmarks): wr = 2^62 means "never underruns, never overruns", as dabx_set_write_pos */
+void orx_set_wr(orx_t *s, int64_t wr) { s->wr = wr; }
 void orx_get_spectrum(const orx_t *s, float *out) { memcpy(out, s->spectrum, sizeof s->spectrum); }
 void orx_get_null_spectrum(const orx_t *s, float *out) { memcpy(out, s->null_spectrum, sizeof s->null_spectrum); }
 void orx_get_state(const orx_t *s, int64_t *st)
@@ -496,27 +500,67 @@ static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *f
 /* ------------------------------------------------------------------ Viterbi
  * x4: 4 soft values per step (0 where punctured), positive = bit 0.
  * States: bit 5 newest … bit 0 oldest.  Metric = correlation, maximised.
- * Tie rule: keep the predecessor whose oldest bit equals the new input bit. */
+ * Tie rule: keep the predecessor whose oldest bit equals the new input bit.
+ *
+ * The textbook recursion, organised so that the scalar code is a fair CPU baseline
+ * (bench.py cpu_baseline): the encoder outputs of the two predecessors of every state are
+ * tabulated once, the 16 branch metrics of a step are built from 8 sums and their negations,
+ * and the scratch buffers are per-thread and grow-only (no malloc per codeword). */
+static uint8_t vit_c[32];                       /* encoder output of the transition 2j -> j (input bit 0) */
+static int vit_ready;
+static void vit_init(void)
+{
+    if (vit_ready) return;
+    for (int j = 0; j < 32; j++) {
+        /* butterfly j: predecessors 2j, 2j+1 -> successors j (input 0) and j+32 (input 1).  All four
+         * generators tap the newest and the oldest register bit, so the four branch words are c, ~c, ~c, c */
+        int c = dab_conv_output(2 * j, 0);
+        if (dab_conv_output(2 * j + 1, 0) != (c ^ 15) || dab_conv_output(2 * j, 1) != (c ^ 15) || dab_conv_output(2 * j + 1, 1) != c) abort();
+        vit_c[j] = (uint8_t)c;
+    }
+    __atomic_store_n(&vit_ready, 1, __ATOMIC_RELEASE);
+}
+static __thread uint64_t *vit_dec;
+static __thread int vit_dec_cap;
+static __thread int8_t *cw_x4;
+static __thread uint8_t *cw_bits;
+static __thread int cw_cap;
+
 void orx_viterbi(const int8_t *x4, int nsteps, uint8_t *bits)
 {
-    int32_t pm[64], nm[64];
-    uint64_t *dec = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nsteps);
+    int32_t pm[64], nm[64], m[32];
+    uint8_t tk[64];
+    vit_init();
+    if (nsteps > vit_dec_cap) {
+        free(vit_dec);
+        vit_dec = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nsteps);
+        vit_dec_cap = nsteps;
+    }
+    uint64_t *dec = vit_dec;
     for (int s = 0; s < 64; s++) pm[s] = PM_INIT;
     pm[0] = 0;
     for (int t = 0; t < nsteps; t++) {
         const int8_t *x = x4 + 4 * t;
         int32_t bm[16];
-        for (int c = 0; c < 16; c++)
-            bm[c] = ((c & 8) ? -x[0] : x[0]) + ((c & 4) ? -x[1] : x[1]) + ((c & 2) ? -x[2] : x[2]) + ((c & 1) ? -x[3] : x[3]);
-        uint64_t d = 0;
-        for (int ns = 0; ns < 64; ns++) {
-            int u = ns >> 5;
-            int own = ((ns << 1) & 63) | u, oth = own ^ 1;
-            int32_t keep = pm[own] + bm[dab_conv_output(own, u)];
-            int32_t recv = pm[oth] + bm[dab_conv_output(oth, u)];
-            if (recv > keep) { nm[ns] = recv; d |= 1ULL << ns; } else nm[ns] = keep;
+        for (int c = 0; c < 8; c++) {           /* bm[c] = sum over j of (bit j of c set ? -x[j] : x[j]); bm[15 - c] = -bm[c] */
+            int32_t v = x[0] + ((c & 4) ? -x[1] : x[1]) + ((c & 2) ? -x[2] : x[2]) + ((c & 1) ? -x[3] : x[3]);
+            bm[c] = v; bm[15 - c] = -v;
+        }
+        for (int j = 0; j < 32; j++) m[j] = bm[vit_c[j]];
+        for (int j = 0; j < 32; j++) {
+            /* successor j (input 0): keeps 2j, receives 2j+1; successor j+32 (input 1): keeps 2j+1, receives 2j */
+            int32_t a = pm[2 * j], b = pm[2 * j + 1], mj = m[j];
+            int32_t k0 = a + mj, r0 = b - mj, k1 = b + mj, r1 = a - mj;
+            tk[j] = (uint8_t)(r0 > k0); nm[j] = r0 > k0 ? r0 : k0;
+            tk[j + 32] = (uint8_t)(r1 > k1); nm[j + 32] = r1 > k1 ? r1 : k1;
         }
         memcpy(pm, nm, sizeof pm);
+        uint64_t d = 0;
+        for (int g = 0; g < 8; g++) {           /* eight 0/1 bytes -> eight bits */
+            uint64_t w;
+            memcpy(&w, tk + 8 * g, 8);
+            d |= ((w * 0x0102040810204080ULL) >> 56) << (8 * g);
+        }
         dec[t] = d;
     }
     int st = 0;                                         /* terminated trellis */
@@ -526,15 +570,21 @@ void orx_viterbi(const int8_t *x4, int nsteps, uint8_t *bits)
         int own = ((st << 1) & 63) | u;
         st = ((dec[t] >> st) & 1) ? (own ^ 1) : own;
     }
-    free(dec);
 }
 
 /* depuncture one codeword through a caller-supplied soft-bit getter */
 typedef int8_t (*soft_fn)(const void *ctx, int i);
 static void decode_cw(const uint32_t *info, int nsteps, int n_in, soft_fn get, const void *ctx, uint8_t *out_bytes)
 {
-    int8_t *x4 = (int8_t *)calloc((size_t)nsteps, 4);
-    uint8_t *bits = (uint8_t *)malloc((size_t)nsteps);
+    if (nsteps > cw_cap) {
+        free(cw_x4); free(cw_bits);
+        cw_x4 = (int8_t *)malloc((size_t)nsteps * 4);
+        cw_bits = (uint8_t *)malloc((size_t)nsteps);
+        cw_cap = nsteps;
+    }
+    int8_t *x4 = cw_x4;
+    uint8_t *bits = cw_bits;
+    memset(x4, 0, (size_t)nsteps * 4);
     for (int t = 0; t < nsteps; t++) {
         int off = (int)(info[t] >> 4), k = 0;
         for (int j = 0; j < 4; j++)
@@ -546,7 +596,6 @@ static void decode_cw(const uint32_t *info, int nsteps, int n_in, soft_fn get, c
         for (int b = 0; b < 8; b++) v = (v << 1) | (unsigned)(bits[8 * i + b] ^ T.prbs[8 * i + b]);
         out_bytes[i] = (uint8_t)v;
     }
-    free(bits); free(x4);
 }
 
 typedef struct { const int8_t *p; } lin_ctx;
@@ -589,7 +638,7 @@ int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8
     int64_t need = s->pos + (int64_t)(n_frames + (wide ? 1 : 0)) * DAB_TF + 4096;
     if (need > s->wr) return -1;
     if (15 + 4 * n_frames > s->ti_slots) return -3;
-    if (s->wr - s->pos > s->ring_len) return -2;
+    if (s->wr < ((int64_t)1 << 62) && s->wr - s->pos > s->ring_len) return -2;
     if (wide) {
         int64_t ns;
         if (!null_search(s, s->pos, &ns)) {

@@ -9,28 +9,12 @@
  * The reference has no transmitter; conventions follow SURVEY.md Appendix B.
  */
 #include "dab_spec.h"
+#include "dab_tx.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct {
-    uint64_t seed;
-    int32_t  eid;          /* ensemble id                              */
-    int32_t  n_frames;
-    int32_t  n_subch;      /* sub-channels; cfg in subch[] below       */
-    int32_t  delay;        /* noise-only samples before frame 0        */
-    int32_t  loop;         /* 1: periodic signal, TI history wraps     */
-    int32_t  fmt;          /* 0: u8 IQ, 1: s16 IQ                      */
-    double   snr_db;       /* >= 100: noiseless                        */
-    double   cfo_hz;
-    double   rms;          /* complex RMS of the signal in LSB         */
-    int32_t  subch[64][4]; /* {start_cu, option(0=A,1=B,2=UEP), level, kbps} */
-    int32_t  payload_given;/* 1: msc_out already holds the payload to transmit    */
-    int32_t  tii_main, tii_sub; /* TII in every null symbol (EN 300 401 §14.8); main < 0: none */
-    int32_t  extra_figs;   /* 1: also send FIG 0/5, 0/8, 0/13, 0/17, 0/18, 0/19 for the first service */
-    int32_t  packet_sub;   /* >= 1: this sub-channel is a packet-mode data component (SCId 0x200 + index, packet address 0x155,
-                              user application 7 = SPI) of the FIRST service, announced by FIG 0/2 (TMId 3), 0/3 and 0/13; 0 = none */
-} dab_tx_cfg_t;
+
 
 /* ---- deterministic PRNG (splitmix64) ---- */
 static uint64_t sm64(uint64_t *s)
@@ -267,13 +251,20 @@ int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *
     dab_freq_interleaver(kofn);
     dab_prs_quadrants(prsq);
     int nfig = build_figs(c, prof, figs), nextfig = 0;
+    /* optional second ensemble (EId + 1) from frame eid2_from on: same multiplex, its own FIG 0/0 and labels */
+    fig_t *figs2 = (fig_t *)calloc(256, sizeof(fig_t));
+    int nfig2 = 0, nextfig2 = 0;
+    if (c->eid2_from > 0) { dab_tx_cfg_t c2 = *c; c2.eid = c->eid + 1; nfig2 = build_figs(&c2, prof, figs2); }
 
     /* ---- FIC: 4 codewords of 3 FIBs per frame ---- */
     for (int f = 0; f < NF; f++)
         for (int cw = 0; cw < DAB_FIC_CW; cw++) {
             uint8_t *fibs = fib_out + ((size_t)f * 12 + 3 * cw) * DAB_FIB_BYTES;
-            for (int j = 0; j < 3; j++)
-                build_fib(fibs + j * DAB_FIB_BYTES, j == 0, c->eid, f * 4 + cw, figs, nfig, &nextfig);
+            const int second = c->eid2_from > 0 && f >= c->eid2_from;
+            for (int j = 0; j < 3; j++) {
+                if (second) build_fib(fibs + j * DAB_FIB_BYTES, j == 0, c->eid + 1, f * 4 + cw, figs2, nfig2, &nextfig2);
+                else build_fib(fibs + j * DAB_FIB_BYTES, j == 0, c->eid, f * 4 + cw, figs, nfig, &nextfig);
+            }
             encode_cw(&ficp, fibs, prbs, ficbits + (size_t)f * DAB_FIC_BITS + cw * DAB_FIC_CW_BITS, tmp_bits, tmp_mother);
         }
     /* ---- MSC logical frames ---- */
@@ -288,18 +279,16 @@ int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *
             encode_cw(&prof[s], pay, prbs, coded + (size_t)r * DAB_CIF_BITS + c->subch[s][0] * DAB_CU_BITS, tmp_bits, tmp_mother);
         }
 
-    /* ---- modulation ---- */
+    /* ---- modulation: the clean complex baseband signal of the whole recording ---- */
     const double amp = c->rms * DAB_TU / sqrt((double)DAB_K);
     const double nsig = (c->snr_db >= 100.0) ? 0.0 : c->rms * pow(10.0, -c->snr_db / 20.0) / sqrt(2.0);
     const double lim_lo = c->fmt ? -32768.0 : 0.0, lim_hi = c->fmt ? 32767.0 : 255.0, bias = c->fmt ? 0.0 : 128.0;
     const size_t total = (size_t)c->delay + (size_t)NF * DAB_TF;
-    double *frame = (double *)malloc(sizeof(double) * 2 * DAB_TF);
-    size_t nabs = 0;
-    for (int f = -1; f < NF; f++) {
-        size_t len = (f < 0) ? (size_t)c->delay : DAB_TF;
-        if (len == 0) continue;
-        memset(frame, 0, sizeof(double) * 2 * len);
-        if (f >= 0 && c->tii_main >= 0) {
+    if (c->loop && c->sco_ppm != 0.0) return -5;
+    double *sig = (double *)calloc(2 * total, sizeof(double));
+    for (int f = 0; f < NF; f++) {
+        double *frame = sig + 2 * ((size_t)c->delay + (size_t)f * DAB_TF);
+        if (c->tii_main >= 0) {
             /* TII: carrier pairs k, k+1 with k = base + 2c + 48b carry the PRS phase of carrier k */
             static const int base[4] = {-768, -384, 1, 385};
             int word = -1, cnt = 0;
@@ -319,56 +308,112 @@ int dab_tx_generate(const dab_tx_cfg_t *c, void *iq, uint8_t *fib_out, uint8_t *
                 frame[2 * n] = re[src] * amp / DAB_TU; frame[2 * n + 1] = im[src] * amp / DAB_TU;
             }
         }
-        if (f >= 0) {
-            for (int b = 0; b < DAB_TU; b++) ph8[b] = (uint8_t)(prsq[b] < 0 ? 0 : 2 * prsq[b]);
-            for (int l = 0; l < DAB_NSYM; l++) {
-                if (l > 0) {
-                    if (l <= DAB_FIC_SYMS) memcpy(symbits, ficbits + (size_t)f * DAB_FIC_BITS + (l - 1) * DAB_SYM_BITS, DAB_SYM_BITS);
-                    else {
-                        int t = f * DAB_CIFS + (l - 4) / DAB_CIF_SYMS;           /* transmitted CIF index */
-                        int base = ((l - 4) % DAB_CIF_SYMS) * DAB_SYM_BITS;
-                        for (int i = 0; i < DAB_SYM_BITS; i++) {
-                            int r = t - dab_ti_delay(base + i);
-                            if (r < 0) r = c->loop ? r + NC : -1;
-                            symbits[i] = (r < 0) ? 0 : coded[(size_t)r * DAB_CIF_BITS + base + i];
-                        }
-                    }
-                    for (int n = 0; n < DAB_K; n++) {
-                        int b = kofn[n] & 2047;
-                        int y = symbits[n] ? (symbits[n + DAB_K] ? 5 : 3) : (symbits[n + DAB_K] ? 7 : 1);
-                        ph8[b] = (uint8_t)((ph8[b] + y) & 7);
+        for (int b = 0; b < DAB_TU; b++) ph8[b] = (uint8_t)(prsq[b] < 0 ? 0 : 2 * prsq[b]);
+        for (int l = 0; l < DAB_NSYM; l++) {
+            if (l > 0) {
+                if (l <= DAB_FIC_SYMS) memcpy(symbits, ficbits + (size_t)f * DAB_FIC_BITS + (l - 1) * DAB_SYM_BITS, DAB_SYM_BITS);
+                else {
+                    int t = f * DAB_CIFS + (l - 4) / DAB_CIF_SYMS;           /* transmitted CIF index */
+                    int base = ((l - 4) % DAB_CIF_SYMS) * DAB_SYM_BITS;
+                    for (int i = 0; i < DAB_SYM_BITS; i++) {
+                        int r = t - dab_ti_delay(base + i);
+                        if (r < 0) r = c->loop ? r + NC : -1;
+                        symbits[i] = (r < 0) ? 0 : coded[(size_t)r * DAB_CIF_BITS + base + i];
                     }
                 }
-                for (int b = 0; b < DAB_TU; b++) {
-                    if (prsq[b] < 0) { re[b] = im[b] = 0.0; continue; }
-                    static const double c8[8] = {1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2, 0, M_SQRT1_2};
-                    re[b] = c8[ph8[b]]; im[b] = c8[(ph8[b] + 6) & 7];
-                }
-                ifft2048(re, im, tw);
-                double *o = frame + 2 * ((size_t)DAB_TNULL + (size_t)l * DAB_TS);
-                for (int n = 0; n < DAB_TS; n++) {
-                    int src = (n + DAB_TU - DAB_TG) & (DAB_TU - 1);
-                    o[2 * n] = re[src] * amp / DAB_TU; o[2 * n + 1] = im[src] * amp / DAB_TU;
+                for (int n = 0; n < DAB_K; n++) {
+                    int b = kofn[n] & 2047;
+                    int y = symbits[n] ? (symbits[n + DAB_K] ? 5 : 3) : (symbits[n + DAB_K] ? 7 : 1);
+                    ph8[b] = (uint8_t)((ph8[b] + y) & 7);
                 }
             }
-        }
-        for (size_t n = 0; n < len; n++, nabs++) {
-            double xr = frame[2 * n], xi = frame[2 * n + 1];
-            if (c->cfo_hz != 0.0) {
-                double a = 2.0 * M_PI * fmod(c->cfo_hz * (double)nabs / DAB_FS, 1.0);
-                double cr = cos(a), ci = sin(a), t = xr * cr - xi * ci;
-                xi = xr * ci + xi * cr; xr = t;
+            for (int b = 0; b < DAB_TU; b++) {
+                if (prsq[b] < 0) { re[b] = im[b] = 0.0; continue; }
+                static const double c8[8] = {1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2, 0, M_SQRT1_2};
+                re[b] = c8[ph8[b]]; im[b] = c8[(ph8[b] + 6) & 7];
             }
-            if (nsig > 0.0) { double g1, g2; gauss2(&nrng, &g1, &g2); xr += nsig * g1; xi += nsig * g2; }
-            double qr = floor(xr + 0.5) + bias, qi = floor(xi + 0.5) + bias;
-            qr = qr < lim_lo ? lim_lo : (qr > lim_hi ? lim_hi : qr);
-            qi = qi < lim_lo ? lim_lo : (qi > lim_hi ? lim_hi : qi);
-            if (c->fmt) { ((int16_t *)iq)[2 * nabs] = (int16_t)qr; ((int16_t *)iq)[2 * nabs + 1] = (int16_t)qi; }
-            else { ((uint8_t *)iq)[2 * nabs] = (uint8_t)qr; ((uint8_t *)iq)[2 * nabs + 1] = (uint8_t)qi; }
+            ifft2048(re, im, tw);
+            double *o = frame + 2 * ((size_t)DAB_TNULL + (size_t)l * DAB_TS);
+            for (int n = 0; n < DAB_TS; n++) {
+                int src = (n + DAB_TU - DAB_TG) & (DAB_TU - 1);
+                o[2 * n] = re[src] * amp / DAB_TU; o[2 * n + 1] = im[src] * amp / DAB_TU;
+            }
         }
     }
-    (void)total;
-    free(tw); free(frame); free(re); free(im); free(figs); free(ficbits); free(coded);
+    /* ---- channel: second path (echo), then the receiver's sampling clock ---- */
+    if (c->echo_db > 0.0 && c->echo_delay > 0) {
+        const double a = pow(10.0, -c->echo_db / 20.0), er = a * cos(c->echo_phase), ei = a * sin(c->echo_phase);
+        const size_t D = (size_t)c->echo_delay, span = (size_t)NF * DAB_TF;
+        double *y = (double *)malloc(sizeof(double) * 2 * total);
+        memcpy(y, sig, sizeof(double) * 2 * total);
+        for (size_t n = (size_t)c->delay; n < total; n++) {
+            size_t m;
+            if (n - (size_t)c->delay >= D) m = n - D;
+            else if (c->loop) m = n + span - D;               /* periodic signal: the echo wraps */
+            else continue;
+            y[2 * n] += sig[2 * m] * er - sig[2 * m + 1] * ei;
+            y[2 * n + 1] += sig[2 * m] * ei + sig[2 * m + 1] * er;
+        }
+        free(sig); sig = y;
+    }
+    if (c->sco_ppm != 0.0) {
+        /* recording sample n = signal at time n (1 + sco) / Fs: Kaiser-windowed sinc, 2 x 24 taps
+         * (signal bandwidth 0.75 Nyquist; interpolation error below -70 dB) */
+        enum { HT = 24, NPH = 1024 };
+        const double eps = c->sco_ppm * 1e-6, beta = 9.0;
+        double *y = (double *)calloc(2 * total, sizeof(double));
+        double *tab = (double *)malloc(sizeof(double) * (NPH + 1) * 2 * HT);   /* tab[p][j]: tap k = j - HT + 1 at fraction p / NPH */
+        double i0b = 1.0;
+        { double t = 1.0; for (int k = 1; k < 60; k++) { t *= (beta / 2.0 / k) * (beta / 2.0 / k); i0b += t; } }
+        for (int p = 0; p <= NPH; p++)
+            for (int j = 0; j < 2 * HT; j++) {
+                const double x = (double)(j - HT + 1) - (double)p / NPH, u = x / (double)HT;
+                double w = 0.0;
+                if (u > -1.0 && u < 1.0) {
+                    const double z = beta * sqrt(1.0 - u * u);
+                    double t = 1.0, sum = 1.0;
+                    for (int q = 1; q < 60; q++) { t *= (z / 2.0 / q) * (z / 2.0 / q); sum += t; }
+                    w = sum / i0b;
+                }
+                tab[p * 2 * HT + j] = (fabs(x) < 1e-12 ? 1.0 : sin(M_PI * x) / (M_PI * x)) * w;
+            }
+        for (size_t n = 0; n < total; n++) {
+            const double pos = (double)n * (1.0 + eps);
+            const long i0 = (long)floor(pos);
+            const double fr = (pos - (double)i0) * NPH;
+            const int p0 = (int)fr;
+            const double a1 = fr - p0, a0 = 1.0 - a1;
+            const double *t0 = tab + (size_t)p0 * 2 * HT, *t1 = t0 + 2 * HT;
+            double ar = 0.0, ai = 0.0;
+            for (int j = 0; j < 2 * HT; j++) {
+                const long m = i0 + j - HT + 1;
+                if (m < 0 || (size_t)m >= total) continue;
+                const double h = a0 * t0[j] + a1 * t1[j];
+                ar += sig[2 * m] * h; ai += sig[2 * m + 1] * h;
+            }
+            y[2 * n] = ar; y[2 * n + 1] = ai;
+        }
+        free(tab);
+        free(sig); sig = y;
+    }
+    /* ---- carrier offset, noise, DC offset, quantisation ---- */
+    for (size_t nabs = 0; nabs < total; nabs++) {
+        double xr = sig[2 * nabs], xi = sig[2 * nabs + 1];
+        if (c->cfo_hz != 0.0) {
+            double a = 2.0 * M_PI * fmod(c->cfo_hz * (double)nabs / DAB_FS, 1.0);
+            double cr = cos(a), ci = sin(a), t = xr * cr - xi * ci;
+            xi = xr * ci + xi * cr; xr = t;
+        }
+        if (nsig > 0.0) { double g1, g2; gauss2(&nrng, &g1, &g2); xr += nsig * g1; xi += nsig * g2; }
+        xr += c->dc_i; xi += c->dc_q;
+        double qr = floor(xr + 0.5) + bias, qi = floor(xi + 0.5) + bias;
+        qr = qr < lim_lo ? lim_lo : (qr > lim_hi ? lim_hi : qr);
+        qi = qi < lim_lo ? lim_lo : (qi > lim_hi ? lim_hi : qi);
+        if (c->fmt) { ((int16_t *)iq)[2 * nabs] = (int16_t)qr; ((int16_t *)iq)[2 * nabs + 1] = (int16_t)qi; }
+        else { ((uint8_t *)iq)[2 * nabs] = (uint8_t)qr; ((uint8_t *)iq)[2 * nabs + 1] = (uint8_t)qi; }
+    }
+    free(sig); free(figs2);
+    free(tw); free(re); free(im); free(figs); free(ficbits); free(coded);
     free(tmp_mother); free(tmp_bits); free(prbs);
     return 0;
 }
