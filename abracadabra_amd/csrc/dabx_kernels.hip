@@ -635,222 +635,121 @@ __device__ __forceinline__ int gather_step(const VitSrc &src, uint32_t w)
     return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
 }
 
-// ---- one add-compare-select step, hand scheduled (6 VALU issues):
-//   S = pm - M, K = pm + M (M = dot4 of the +-1 branch signs with the four soft values),
-//   recv = S of the butterfly partner lane, pm' = max(K, recv); the decision recv > K is the
-//   sign of K - pm'.  gfx950 needs 3 wait states between a DOT write and another VALU's
-//   read of that register (and 2 before a DPP read), so the gap between the dot4 pair and
-//   the DPP max is filled with useful work: the next step's v_readlane and the PREVIOUS
-//   step's decision (Kp - pm, shifted into `bits`).  A run therefore starts with Kp = pm
-//   (a dummy 0 decision that is later shifted out) and ends with acs_flush().
-//   (v_subrev_u32_dpp is not usable for K - recv: measured on gfx950 it swizzles the
-//   minuend, like v_sub_u32_dpp.)
-#define DABX_ACS_DPP(CTRL)                                                                        \
-    asm volatile("v_dot4_i32_i8 %[S], %[nsig], %[xs], %[pm]\n\t"                                  \
-                 "v_dot4_i32_i8 %[K], %[sig], %[xs], %[pm]\n\t"                                   \
-                 "v_readlane_b32 %[xn], %[xv], %[idx]\n\t"                                        \
-                 "v_sub_u32 %[D], %[Kp], %[pm]\n\t"                                               \
-                 "v_alignbit_b32 %[bits], %[bits], %[D], 31\n\t"                                  \
-                 "v_max_i32_dpp %[pm], %[S], %[K] " CTRL " row_mask:0xf bank_mask:0xf"            \
-                 : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D), [xn] "=&s"(xn) \
-                 : [sig] "v"(sig), [nsig] "v"(nsig), [xs] "s"(xs), [xv] "v"(xv), [idx] "s"(idx), [Kp] "v"(Kp))
-
-#define DABX_ACS_LDS(EXCH, ...)                                                                   \
-    asm volatile("v_dot4_i32_i8 %[S], %[nsig], %[xs], %[pm]\n\t"                                  \
-                 "v_dot4_i32_i8 %[K], %[sig], %[xs], %[pm]\n\t"                                   \
-                 "v_readlane_b32 %[xn], %[xv], %[idx]\n\t"                                        \
-                 "v_sub_u32 %[D], %[Kp], %[pm]\n\t"                                               \
-                 "v_alignbit_b32 %[bits], %[bits], %[D], 31\n\t"                                  \
-                 EXCH "\n\t"                                                                      \
-                 "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-                 "v_max_i32 %[pm], %[K], %[D]"                                                    \
-                 : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D), [xn] "=&s"(xn) \
-                 : [sig] "v"(sig), [nsig] "v"(nsig), [xs] "s"(xs), [xv] "v"(xv), [idx] "s"(idx), [Kp] "v"(Kp), [ad] "v"(lane_x32) __VA_ARGS__)
-
-template <int PH>
-__device__ __forceinline__ int acs(int &pm, int &Kp, int sig, int nsig, int xs, int xv, int idx, int lane_x32, uint32_t &bits)
-{
-    int S, K, D, xn;
-    if (PH == 0) DABX_ACS_DPP("quad_perm:[1,0,3,2]");
-    else if (PH == 1) DABX_ACS_DPP("quad_perm:[2,3,0,1]");
-    else if (PH == 2) DABX_ACS_DPP("row_half_mirror");
-    else if (PH == 3) DABX_ACS_DPP("row_ror:8");
-    else if (PH == 4) DABX_ACS_LDS("ds_swizzle_b32 %[D], %[S] offset:swizzle(SWAP,16)");
-    else DABX_ACS_LDS("ds_bpermute_b32 %[D], %[ad], %[S]");
-    Kp = K;
-    return xn;
-}
-
-// decision of the last step of a run
-__device__ __forceinline__ void acs_flush(int pm, int Kp, uint32_t &bits)
-{
-    int D;
-    asm volatile("v_sub_u32 %[D], %[Kp], %[pm]\n\t"
-                 "v_alignbit_b32 %[bits], %[bits], %[D], 31"
-                 : [bits] "+v"(bits), [D] "=&v"(D) : [Kp] "v"(Kp), [pm] "v"(pm));
-}
-
-// cnt (1..32) steps starting at lane s0 of xv, the first one in phase PH0
-template <int PH0>
-__device__ __forceinline__ void acs_run(int &pm, const int *sig, const int *nsig, int xv, int s0, int cnt, int lane_x32,
-                                        uint32_t &bits)
-{
-    int xs, Kp;
-    // first soft-value word of the run; Kp = pm makes the first (dummy) decision 0.
-    // The nop covers the VALU-writes-SGPR -> VALU-reads hazard of xs.
-    asm volatile("v_readlane_b32 %0, %2, %3\n\tv_mov_b32 %1, %4\n\ts_nop 1" : "=s"(xs), "=&v"(Kp) : "v"(xv), "s"(s0), "v"(pm));
-    int s = 0;
-#define DABX_STEP(J) xs = acs<(PH0 + J) % 6>(pm, Kp, sig[(PH0 + J) % 6], nsig[(PH0 + J) % 6], xs, xv, s0 + s + J + 1, lane_x32, bits)
-    for (; s + 6 <= cnt; s += 6) {
-        DABX_STEP(0); DABX_STEP(1); DABX_STEP(2); DABX_STEP(3); DABX_STEP(4); DABX_STEP(5);
-    }
-    const int rem = cnt - s;                       // 0..5 steps left, statically phased
-    if (rem > 0) DABX_STEP(0);
-    if (rem > 1) DABX_STEP(1);
-    if (rem > 2) DABX_STEP(2);
-    if (rem > 3) DABX_STEP(3);
-    if (rem > 4) DABX_STEP(4);
-#undef DABX_STEP
-    acs_flush(pm, Kp, bits);
-}
-
-// 32 consecutive steps in ONE asm statement (text generated by tools/gen_acs32.py): no
-// compiler-inserted pads between steps.  The soft values of step j sit in lane base + j of xv
-// (vb = 4 * base in every lane); each is broadcast to all lanes by a ds_bpermute three steps
-// ahead of its use — the LDS crossbar does that without a VALU issue, unlike v_readlane.
-// bits must be 0 on entry and holds the 32 decisions on exit.
+// ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py), 4 VALU issues per step:
+//   T = pm | (1 << ph)            tag "kept at phase ph" (path metrics are scaled by 64: their low six bits are free)
+//   K = T + 64 M, S = pm - 64 M   (M = dot4 of the +-1 branch signs with the four soft values; the sign tables hold +-64)
+//   pm' = max(K, S of the butterfly partner lane)
+// The tags sit in the low bits of the metric, so they travel with the survivor through the max: after the six
+// steps of a group (phases 0..5) the low six bits of a lane's metric are the keep(1)/receive(0) history of ITS
+// survivor path over those six steps.  They are shifted into the lane's decision word (v_alignbit) and cleared.
+// A metric tie keeps the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag
+// bits are still zero.  Range: |metric| <= 27654 steps x 4 x 127 x 64 < 2^31.
+// gfx950 needs 3 wait states between a DOT write and another VALU's read of that register (2 before a DPP read).
+// The soft values of step j sit in lane base + j of xv (vb = 4 * base in every lane); each is broadcast to all lanes
+// by a ds_bpermute three steps ahead of its use — the LDS crossbar does that without a VALU issue.
 #include "dabx_acs32.inc"
-template <int PH0>
-__device__ __forceinline__ void acs32(int &pm, const int *sig, const int *nsig, int xv, int vb, int lane_x32, uint32_t &bits)
-{
-    int S, Ka, Kb, D, X0, X1, X2, X3;
-#define DABX_ACS32_OPS                                                                                              \
-    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [Ka] "=&v"(Ka), [Kb] "=&v"(Kb), [D] "=&v"(D), [X0] "=&v"(X0), \
+#define DABX_ACS_OPS                                                                                                \
+    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [T] "=&v"(T), [D] "=&v"(D), [X0] "=&v"(X0),     \
       [X1] "=&v"(X1), [X2] "=&v"(X2), [X3] "=&v"(X3)                                                                \
-    : [xv] "v"(xv), [vb] "v"(vb), [ad] "v"(lane_x32), [s0] "v"(sig[0]), [s1] "v"(sig[1]), [s2] "v"(sig[2]),         \
-      [s3] "v"(sig[3]), [s4] "v"(sig[4]), [s5] "v"(sig[5]), [n0] "v"(nsig[0]), [n1] "v"(nsig[1]), [n2] "v"(nsig[2]), \
-      [n3] "v"(nsig[3]), [n4] "v"(nsig[4]), [n5] "v"(nsig[5])                                                       \
+    : [xv] "v"(xv), [vb] "v"(vb), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),            \
+      [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5]), [s0] "v"(ss[0]), [s1] "v"(ss[1]), [s2] "v"(ss[2]),         \
+      [s3] "v"(ss[3]), [s4] "v"(ss[4]), [s5] "v"(ss[5])                                                             \
     : "memory"
-    if (PH0 == 0) asm volatile(DABX_ACS32_TEXT_0 DABX_ACS32_OPS);
-    else if (PH0 == 2) asm volatile(DABX_ACS32_TEXT_2 DABX_ACS32_OPS);
-    else asm volatile(DABX_ACS32_TEXT_4 DABX_ACS32_OPS);
-#undef DABX_ACS32_OPS
-}
-
-// Traceback of the 96 steps [96 g, 96 g + 96) on the scalar unit.  A = survivor position in
-// basis coordinates after step 96 g + 95.  Inside six steps of phases 5..0 every bit of A is
-// read (it is that step's decoded bit) before it is toggled, so A at the top of a group IS
-// the six decoded bits of the group: bit q = step 6 grp + q.
-__device__ __forceinline__ uint32_t traceback96(const uint32_t *dec, int g, int lane, uint32_t A,
-                                                const uint32_t *__restrict__ prbs32, uint32_t *out32)
+// one decision word: five groups = 30 steps starting at lane (vb / 4) of xv
+__device__ __forceinline__ void acs30(int &pm, const int *sk, const int *ss, int xv, int vb, int lane_x32, uint32_t &bits)
 {
-    uint32_t w[3], o[3] = {0u, 0u, 0u};                  // o[k]: step 32 k + j at bit 31 - j
-#pragma unroll
-    for (int k = 0; k < 3; ++k) w[k] = dec[(3 * g + k) * 64 + lane];
-#pragma unroll
-    for (int grp = 15; grp >= 0; --grp) {
-        const uint32_t rev = __builtin_bitreverse32(A) >> 26;        // step 6 grp + q at bit 5 - q
-        const int f = 6 * grp, k = f >> 5, off = f & 31;
-        if (off + 6 <= 32) o[k] |= rev << (26 - off);
-        else {
-            const int n1 = off + 6 - 32;                              // bits that spill into the next word
-            o[k] |= rev >> n1;
-            o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
-        }
-#pragma unroll
-        for (int q = 5; q >= 0; --q) {
-            const int t = f + q, pos = 31 - (t & 31);
-            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)w[t >> 5], (int)A);
-            A ^= ((pos >= q) ? (x >> (pos - q)) : (x << (q - pos))) & (1u << q);
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out32[3 * g + k] = __builtin_bswap32(o[k] ^ prbs32[3 * g + k]);
-    }
-    return A;
+    int S, K, T, D, X0, X1, X2, X3;
+    asm volatile(DABX_ACS30_TEXT DABX_ACS_OPS);
 }
+// one group of six steps (the last, partial word of a codeword)
+__device__ __forceinline__ void acs6(int &pm, const int *sk, const int *ss, int xv, int vb, int lane_x32, uint32_t &bits)
+{
+    int S, K, T, D, X0, X1, X2, X3;
+    asm volatile(DABX_ACS6_TEXT DABX_ACS_OPS);
+}
+#undef DABX_ACS_OPS
+
+constexpr int VIT_BLK = 60;          // trellis steps per soft-bit fetch block (lanes 0..59 fetch one step each) = two decision words
 
 // Decode one terminated codeword with the calling wave.
-//   dec:    32-bit decision words [half-block of 32 steps][64]: the word of the lane
-//           with basis coordinates A is stored at index A, bit 31-j = step j
+//   dec:    32-bit decision words [word of 30 steps][64]: the word of the lane with basis coordinates A is stored
+//           at index A; the tags of the word's i-th group of six steps sit at bits 2 + 6 i .. 7 + 6 i
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
-//   out:    n_in/8 bytes.  nsteps, n_in and all pointers are wave-uniform.
+//   out:    n_in/8 bytes.  nsteps (= n_in + 6, a multiple of 6), n_in (a multiple of 32) and all pointers are wave-uniform.
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out)
 {
     const int lane = threadIdx.x & 63;
-    int sig[6], nsig[6];
+    int sk[6], ss[6];
 #pragma unroll
     for (int ph = 0; ph < 6; ++ph) {
         int st = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) st |= lane_coord(lane, (i + ph) % 6) << i;
-        int u = st & 1, o = conv_out0(st), sg = 0, ng = 0;
+        int u = st & 1, o = conv_out0(st), kg = 0, sg = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int neg = ((o >> (3 - j)) & 1) ^ u;
-            sg |= (neg ? 0xff : 0x01) << (8 * j);
-            ng |= (neg ? 0x01 : 0xff) << (8 * j);
+            kg |= (neg ? 0xC0 : 0x40) << (8 * j);          // -+64
+            sg |= (neg ? 0x40 : 0xC0) << (8 * j);
         }
-        sig[ph] = sg; nsig[ph] = ng;
+        sk[ph] = kg; ss[ph] = sg;
     }
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
-    int pm = lane == 0 ? 0 : PM_INIT;
-    const int nhb = (nsteps + 31) >> 5;                          // half-blocks of 32 steps
-    // Soft-bit pipeline, three blocks of 64 steps deep: the depuncturing words of block b+2 and
+    int pm = lane == 0 ? 0 : PM_INIT * 64;
+    const int G = nsteps / 6, nwords = (G + 4) / 5;              // groups of six steps, decision words
+    // Soft-bit pipeline, three blocks of 60 steps deep: the depuncturing words of block b+2 and
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
-    int xnext = gather_step(src, step_word(info, lane, nsteps));
-    uint32_t wnext = step_word(info, 64 + lane, nsteps);
-    const int nblk = (nsteps + 63) >> 6;
+    const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 60..63 fetch nothing
+    int xnext = gather_step(src, step_word(info, tl, nsteps));
+    uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
+    const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
     for (int blk = 0; blk < nblk; ++blk) {
         const int xcur = xnext;
         xnext = gather_step(src, wnext);
-        wnext = step_word(info, (blk + 2) * 64 + lane, nsteps);
+        wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int hb = 2 * blk + half;
-            const int cnt = min(32, nsteps - hb * 32);
-            if (cnt <= 0) break;
+            const int w = 2 * blk + half;
+            const int ng = min(5, G - 5 * w);
+            if (ng <= 0) break;
             uint32_t bits = 0;
-            if (cnt == 32) {
-                switch (hb % 3) {                                // (32 hb) mod 6 = 2 (hb mod 3)
-                case 0: acs32<0>(pm, sig, nsig, xcur, 128 * half, lane_x32, bits); break;
-                case 1: acs32<2>(pm, sig, nsig, xcur, 128 * half, lane_x32, bits); break;
-                default: acs32<4>(pm, sig, nsig, xcur, 128 * half, lane_x32, bits); break;
-                }
-            } else {                                             // the 6 tail steps
-                switch (hb % 3) {
-                case 0: acs_run<0>(pm, sig, nsig, xcur, 32 * half, cnt, lane_x32, bits); break;
-                case 1: acs_run<2>(pm, sig, nsig, xcur, 32 * half, cnt, lane_x32, bits); break;
-                default: acs_run<4>(pm, sig, nsig, xcur, 32 * half, cnt, lane_x32, bits); break;
+            if (ng == 5) acs30(pm, sk, ss, xcur, 120 * half, lane_x32, bits);
+            else {
+                for (int gi = 0; gi < ng; ++gi) acs6(pm, sk, ss, xcur, 120 * half + 24 * gi, lane_x32, bits);
+                bits >>= 6 * (5 - ng);
+            }
+            dec[w * 64 + coordA] = bits;
+        }
+    }
+    // ---- traceback on the scalar unit, in basis coordinates, from state 0, six steps per look-up: the position A
+    // at the end of a group IS the group's six decoded bits (bit q = step 6 g + q), and the position six steps
+    // earlier is A ^ ~tags.  The last group is the tail.  Output words (32 steps) are assembled in a 64-bit shift
+    // register, earliest step on top.
+    uint32_t A = 0;
+    uint64_t acc = 0;
+    int cnt = 0, ow = n_in >> 5;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    for (int w = nwords - 1; w >= 0; --w) {
+        const uint32_t word = dec[w * 64 + lane];
+        const int ng = min(5, G - 5 * w);
+        for (int gi = ng - 1; gi >= 0; --gi) {
+            const uint32_t h = ((uint32_t)__builtin_amdgcn_readlane((int)word, (int)A) >> (2 + 6 * gi)) & 63u;
+            if (5 * w + gi < G - 1) {
+                acc = (acc >> 6) | ((uint64_t)(__builtin_bitreverse32(A) >> 26) << 58);
+                cnt += 6;
+                if (cnt >= 32) {
+                    const uint32_t o = (uint32_t)(acc >> (64 - cnt));
+                    --ow;
+                    if (lane == 0) out32[ow] = __builtin_bswap32(o ^ prbs32[ow]);
+                    cnt -= 32;
                 }
             }
-            dec[hb * 64 + coordA] = bits << (32 - cnt);          // cnt >= 1
+            A ^= ~h & 63u;
         }
     }
-    // ---- traceback on the scalar unit, in basis coordinates, from state 0.
-    // The top (nsteps mod 96) steps go through the generic loop, the rest in 96-step blocks.
-    uint32_t A = 0;
-    const int nfast = nsteps / 96;
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
-    for (int hb = nhb - 1; hb >= 3 * nfast; --hb) {
-        const uint32_t word = dec[hb * 64 + lane];
-        const int cnt = min(32, nsteps - hb * 32);
-        uint32_t ph = (uint32_t)(hb * 32 + cnt - 1) % 6u;
-        uint32_t o = 0;
-        for (int j = cnt - 1; j >= 0; --j) {
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)A);
-            const uint32_t d = (w >> (31 - j)) & 1u;
-            o |= ((A >> ph) & 1u) << (31 - j);                   // decoded bit of step 32 hb + j
-            A ^= d << ph;
-            ph = ph == 0 ? 5u : ph - 1u;
-        }
-        if (n_in - hb * 32 > 0 && lane == 0) out32[hb] = __builtin_bswap32(o ^ prbs32[hb]);   // n_in is a multiple of 32
-    }
-    for (int g = nfast - 1; g >= 0; --g) A = traceback96(dec, g, lane, A, prbs32, out32);
 }
 
 }  // namespace
@@ -889,7 +788,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wi >= n_cw) return;
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
-    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps + 31) >> 5) * 64), out + (size_t)wi * (n_in / 8));
+    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps / 6 + 4) / 5) * 64), out + (size_t)wi * (n_in / 8));
 }
 
 // stage-level FFT: one workgroup per vector, natural order in and out

@@ -41,39 +41,47 @@ def sig_tables():
 
 
 def decode(x4):
-    """x4: [nsteps, 4] int soft values (0 = punctured). Returns decoded bits [nsteps]."""
+    """x4: [nsteps, 4] int soft values (0 = punctured), nsteps a multiple of 6.  Returns decoded bits [nsteps].
+
+    Mirrors viterbi_wave(): path metrics are scaled by 64 and the low six bits of a metric carry the keep/receive
+    tags of the last (up to) six steps of ITS survivor path (bit ph = 1: kept at the step of phase ph), so the tags
+    travel with the path through the max.  At the end of a group of six steps the six tags of every lane go into
+    the lane's decision word (five groups = 30 steps per 32-bit word, newest on top) and are cleared.  A tie keeps
+    the own path: the kept candidate has its tag bit set, the received one does not, all higher tag bits are zero.
+    The traceback then walks six steps per look-up: position ^= ~tags."""
     nsteps = len(x4)
+    assert nsteps % 6 == 0
     sig = sig_tables()
     lanes = np.arange(64)
     coordA = lanes ^ (((lanes >> 2) & 1) * 3)
-    pm = np.full(64, PM_INIT, dtype=np.int64)
+    pm = np.full(64, PM_INIT * 64, dtype=np.int64)
     pm[0] = 0
-    nhb = (nsteps + 31) >> 5
-    dec = np.zeros((nhb, 64), dtype=np.uint64)
-    for hb in range(nhb):
-        cnt = min(32, nsteps - hb * 32)
+    G = nsteps // 6
+    nwords = (G + 4) // 5
+    dec = np.zeros((nwords, 64), dtype=np.uint64)
+    for w in range(nwords):
+        ng = min(5, G - 5 * w)
         bits = np.zeros(64, dtype=np.uint64)
-        for j in range(cnt):
-            t = hb * 32 + j
-            ph = t % 6
-            m = sig[ph] @ x4[t].astype(np.int64)
-            keep = pm + m
-            send = pm - m
-            recv = send[lanes ^ XV[ph]]
-            d = (recv > keep).astype(np.uint64)
-            bits = ((bits << np.uint64(1)) | d) & np.uint64(0xFFFFFFFF)
-            pm = np.maximum(keep, recv)
-        word = (bits << np.uint64(32 - cnt)) & np.uint64(0xFFFFFFFF)
-        dec[hb, coordA] = word
+        for gi in range(ng):
+            for ph in range(6):
+                t = (5 * w + gi) * 6 + ph
+                m = 64 * (sig[ph] @ x4[t].astype(np.int64))
+                keep = (pm | (1 << ph)) + m
+                send = pm - m
+                recv = send[lanes ^ XV[ph]]
+                pm = np.maximum(keep, recv)
+                assert np.abs(pm).max() < 2 ** 31
+            bits = (((pm & 63).astype(np.uint64)) << np.uint64(26)) | (bits >> np.uint64(6))     # v_alignbit_b32 bits, pm, bits, 6
+            pm = pm & ~63
+        bits >>= np.uint64(6 * (5 - ng))
+        dec[w, coordA] = bits
     out = np.zeros(nsteps, dtype=np.uint8)
     A = 0
-    for hb in range(nhb - 1, -1, -1):
-        cnt = min(32, nsteps - hb * 32)
-        ph = (hb * 32 + cnt - 1) % 6
-        for j in range(cnt - 1, -1, -1):
-            w = int(dec[hb, A])
-            d = (w >> (31 - j)) & 1
-            out[hb * 32 + j] = (A >> ph) & 1
-            A ^= d << ph
-            ph = 5 if ph == 0 else ph - 1
+    for w in range(nwords - 1, -1, -1):
+        ng = min(5, G - 5 * w)
+        for gi in range(ng - 1, -1, -1):
+            h = (int(dec[w, A]) >> (2 + 6 * gi)) & 63
+            for q in range(6):
+                out[(5 * w + gi) * 6 + q] = (A >> q) & 1
+            A ^= (~h) & 63
     return out
