@@ -645,26 +645,27 @@ __device__ __forceinline__ int gather_step(const VitSrc &src, uint32_t w)
 // A metric tie keeps the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag
 // bits are still zero.  Range: |metric| <= 27654 steps x 4 x 127 x 64 < 2^31.
 // gfx950 needs 3 wait states between a DOT write and another VALU's read of that register (2 before a DPP read).
-// The soft values of step j sit in lane base + j of xv (vb = 4 * base in every lane); each is broadcast to all lanes
-// by a ds_bpermute three steps ahead of its use — the LDS crossbar does that without a VALU issue.
+// The packed soft values of a block of 60 steps are staged in LDS memory by the lanes that gathered them (one dword
+// per step); every lane then reads the same four dwords with one ds_read_b128 per four steps — a broadcast read that
+// costs the LDS pipe 4 cycles per 4 steps.  (A ds_bpermute broadcast per step, as in round 1, made the CU's LDS
+// pipe the bound of the kernel: extra VALU instructions were free.)
 #include "dabx_acs32.inc"
 #define DABX_ACS_OPS                                                                                                \
-    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [T] "=&v"(T), [D] "=&v"(D), [X0] "=&v"(X0),     \
-      [X1] "=&v"(X1), [X2] "=&v"(X2), [X3] "=&v"(X3)                                                                \
-    : [xv] "v"(xv), [vb] "v"(vb), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),            \
+    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [T] "=&v"(T), [D] "=&v"(D)                      \
+    : [va] "v"(va), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),                          \
       [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5]), [s0] "v"(ss[0]), [s1] "v"(ss[1]), [s2] "v"(ss[2]),         \
       [s3] "v"(ss[3]), [s4] "v"(ss[4]), [s5] "v"(ss[5])                                                             \
-    : "memory"
-// one decision word: five groups = 30 steps starting at lane (vb / 4) of xv
-__device__ __forceinline__ void acs30(int &pm, const int *sk, const int *ss, int xv, int vb, int lane_x32, uint32_t &bits)
+    : "memory", DABX_ACS_XCLOBBER
+// one decision word: five groups = 30 steps whose soft values start at LDS byte address va
+__device__ __forceinline__ void acs30(int &pm, const int *sk, const int *ss, uint32_t va, int lane_x32, uint32_t &bits)
 {
-    int S, K, T, D, X0, X1, X2, X3;
+    int S, K, T, D;
     asm volatile(DABX_ACS30_TEXT DABX_ACS_OPS);
 }
 // one group of six steps (the last, partial word of a codeword)
-__device__ __forceinline__ void acs6(int &pm, const int *sk, const int *ss, int xv, int vb, int lane_x32, uint32_t &bits)
+__device__ __forceinline__ void acs6(int &pm, const int *sk, const int *ss, uint32_t va, int lane_x32, uint32_t &bits)
 {
-    int S, K, T, D, X0, X1, X2, X3;
+    int S, K, T, D;
     asm volatile(DABX_ACS6_TEXT DABX_ACS_OPS);
 }
 #undef DABX_ACS_OPS
@@ -676,8 +677,9 @@ constexpr int VIT_BLK = 60;          // trellis steps per soft-bit fetch block (
 //           at index A; the tags of the word's i-th group of six steps sit at bits 2 + 6 i .. 7 + 6 i
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6, a multiple of 6), n_in (a multiple of 32) and all pointers are wave-uniform.
+//   xs:     the wave's staging buffer in LDS: [2 blocks][2 words][32 dwords]
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
-                             const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out)
+                             const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs)
 {
     const int lane = threadIdx.x & 63;
     int sk[6], ss[6];
@@ -703,11 +705,14 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
     const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 60..63 fetch nothing
+    const int xslot = lane < 30 ? lane : (lane < VIT_BLK ? lane + 2 : 30 + (lane & 1));   // word 1 starts 128 bytes in (16-byte aligned reads)
+    const uint32_t xs_addr = (uint32_t)(uintptr_t)xs;            // LDS byte address (the low 32 bits of a shared pointer)
     int xnext = gather_step(src, step_word(info, tl, nsteps));
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
     const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
     for (int blk = 0; blk < nblk; ++blk) {
-        const int xcur = xnext;
+        int *xb = xs + (blk & 1) * 64;
+        xb[xslot] = xnext;                                       // lanes 60..63 write padding
         xnext = gather_step(src, wnext);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
 #pragma unroll
@@ -716,9 +721,10 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
             const int ng = min(5, G - 5 * w);
             if (ng <= 0) break;
             uint32_t bits = 0;
-            if (ng == 5) acs30(pm, sk, ss, xcur, 120 * half, lane_x32, bits);
+            const uint32_t va = xs_addr + (uint32_t)((blk & 1) * 256 + half * 128);
+            if (ng == 5) acs30(pm, sk, ss, va, lane_x32, bits);
             else {
-                for (int gi = 0; gi < ng; ++gi) acs6(pm, sk, ss, xcur, 120 * half + 24 * gi, lane_x32, bits);
+                for (int gi = 0; gi < ng; ++gi) acs6(pm, sk, ss, va + 24u * gi, lane_x32, bits);
                 bits >>= 6 * (5 - ng);
             }
             dec[w * 64 + coordA] = bits;
@@ -763,6 +769,8 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
+    __shared__ __attribute__((aligned(16))) int xs_all[4][128];
+    int *xs = xs_all[wave];
     const DevWork w = work[wi];
     const DevState &st = C.state[w.stream];
     if (st.acq_fail) return;
@@ -770,14 +778,14 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     if (w.sub < 0) {
         VitSrc src = {C.fic_soft + ((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304, 0, -1};
         uint8_t *out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
-        viterbi_wave(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out);
+        viterbi_wave(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out, xs);
     } else {
         const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
         const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
         if (r < 0) return;                           // time de-interleaver still filling (k_finish flags it)
         VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + (sc.start_bit >> 4), r, C.ti_slots - 1};
         uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
-        viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out);
+        viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out, xs);
     }
 }
 
@@ -785,10 +793,12 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
 __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int n_coded, const uint32_t *info, int nsteps,
                                                         int n_in, const uint32_t *prbs, uint32_t *scratch, uint8_t *out, int n_cw)
 {
-    const int wi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
+    __shared__ __attribute__((aligned(16))) int xs_all[4][128];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
-    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps / 6 + 4) / 5) * 64), out + (size_t)wi * (n_in / 8));
+    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps / 6 + 4) / 5) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave]);
 }
 
 // stage-level FFT: one workgroup per vector, natural order in and out
