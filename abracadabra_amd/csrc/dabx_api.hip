@@ -176,10 +176,10 @@ int build_work(dabx_ctx *c, int n_frames)
                                    static_cast<uint32_t>(sh.prof[k].steps())});
         }
     std::stable_sort(all.begin(), all.end(), [](const DevWork &a, const DevWork &b) { return a.nsteps > b.nsteps; });
-    size_t blocks = 0;                                  // in units of 64 words = one decision word (30 steps) per lane
+    size_t blocks = 0;                                  // in units of 64 words = one decision word (24 steps) per lane
     for (auto &w : all) {
         w.scratch = static_cast<uint32_t>(blocks);
-        blocks += (w.nsteps / 6 + 4) / 5;
+        blocks += w.nsteps / 24 + 1;
     }
     if (blocks >> 32) return DABX_E_NOMEM;
     c->n_work = static_cast<int>(all.size());
@@ -676,7 +676,8 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     if (kind != 0 && !dabx::any_profile(option, level, kbps, p)) return DABX_E_PROFILE;
     const auto info = dabx::step_info(p);
     const int nsteps = p.steps();
-    const size_t words = static_cast<size_t>(((nsteps / 6 + 4) / 5) * 64);
+    const size_t words = static_cast<size_t>((nsteps / 24 + 1) * 64);
+    if (nsteps % 48 != 6) return DABX_E_PROFILE;             // every DAB codeword: 48 k + 6 trellis steps
     int8_t *d_soft = nullptr; uint32_t *d_info = nullptr, *d_scr = nullptr; uint8_t *d_out = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_soft), static_cast<size_t>(n_cw) * p.n_coded));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_info), info.size() * 4));

@@ -635,125 +635,135 @@ __device__ __forceinline__ int gather_step(const VitSrc &src, uint32_t w)
     return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
 }
 
-// ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py), 4 VALU issues per step:
-//   T = pm | (1 << ph)            tag "kept at phase ph" (path metrics are scaled by 64: their low six bits are free)
-//   K = T + 64 M, S = pm - 64 M   (M = dot4 of the +-1 branch signs with the four soft values; the sign tables hold +-64)
+// ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
+// Path metrics are scaled by 64, so their low six bits are free: they carry the keep(1)/receive(0) tags of the last
+// (up to) six steps of the lane's SURVIVOR — the tags travel with the path through the max.  Per step, 4 VALU issues:
+//   S = pm - 64 M                 (M = +-x0 +-x1 +-x2 +-x3, the branch metric of the lane's state)
+//   T = pm | (1 << ph)            tag "kept at phase ph"
+//   K = T + 64 M
 //   pm' = max(K, S of the butterfly partner lane)
-// The tags sit in the low bits of the metric, so they travel with the survivor through the max: after the six
-// steps of a group (phases 0..5) the low six bits of a lane's metric are the keep(1)/receive(0) history of ITS
-// survivor path over those six steps.  They are shifted into the lane's decision word (v_alignbit) and cleared.
-// A metric tie keeps the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag
-// bits are still zero.  Range: |metric| <= 27654 steps x 4 x 127 x 64 < 2^31.
-// gfx950 needs 3 wait states between a DOT write and another VALU's read of that register (2 before a DPP read).
-// The packed soft values of a block of 60 steps are staged in LDS memory by the lanes that gathered them (one dword
-// per step); every lane then reads the same four dwords with one ds_read_b128 per four steps — a broadcast read that
-// costs the LDS pipe 4 cycles per 4 steps.  (A ds_bpermute broadcast per step, as in round 1, made the CU's LDS
-// pipe the bound of the kernel: extra VALU instructions were free.)
+// After the six steps of a group (phases 0..5) the low six bits of a lane's metric are the history of ITS survivor
+// over those six steps; they are shifted into the lane's decision word (v_alignbit) and cleared.  A metric tie keeps
+// the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag bits are still zero.
+// Range: |metric| <= 27654 steps x 4 x 127 x 64 < 2^31.
+// The 64 M of 24 steps come from six v_mfma_i32_4x4x4_16b_i8 (one per phase, see tools/gen_acs32.py): the matrix
+// core is otherwise idle and the vector ALU is what bounds this kernel.  Their A operands are the packed soft values
+// of the chunk, staged in LDS memory by the lanes that gathered them: lane l reads step ph + 6 (l mod 4).
 #include "dabx_acs32.inc"
 #define DABX_ACS_OPS                                                                                                \
     : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [T] "=&v"(T), [D] "=&v"(D)                      \
     : [va] "v"(va), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),                          \
-      [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5]), [s0] "v"(ss[0]), [s1] "v"(ss[1]), [s2] "v"(ss[2]),         \
-      [s3] "v"(ss[3]), [s4] "v"(ss[4]), [s5] "v"(ss[5])                                                             \
-    : "memory", DABX_ACS_XCLOBBER
-// one decision word: five groups = 30 steps whose soft values start at LDS byte address va
-__device__ __forceinline__ void acs30(int &pm, const int *sk, const int *ss, uint32_t va, int lane_x32, uint32_t &bits)
+      [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5])                                                             \
+    : "memory", DABX_ACS_CLOBBER
+// one chunk: four groups = 24 steps; va = LDS byte address of the chunk's first soft-value dword + 24 (lane mod 4)
+__device__ __forceinline__ void acs24(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
     int S, K, T, D;
-    asm volatile(DABX_ACS30_TEXT DABX_ACS_OPS);
+    asm volatile(DABX_ACS24_TEXT DABX_ACS_OPS);
 }
-// one group of six steps (the last, partial word of a codeword)
-__device__ __forceinline__ void acs6(int &pm, const int *sk, const int *ss, uint32_t va, int lane_x32, uint32_t &bits)
+// one group of six steps (the tail of a codeword)
+__device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
     int S, K, T, D;
     asm volatile(DABX_ACS6_TEXT DABX_ACS_OPS);
 }
 #undef DABX_ACS_OPS
 
-constexpr int VIT_BLK = 60;          // trellis steps per soft-bit fetch block (lanes 0..59 fetch one step each) = two decision words
+constexpr int VIT_BLK = 48;          // trellis steps per soft-bit fetch block (lanes 0..47 fetch one step each) = two chunks
 
-// Decode one terminated codeword with the calling wave.
-//   dec:    32-bit decision words [word of 30 steps][64]: the word of the lane with basis coordinates A is stored
-//           at index A; the tags of the word's i-th group of six steps sit at bits 2 + 6 i .. 7 + 6 i
+// Decode one terminated codeword with the calling wave.  Every DAB codeword has 48 k + 6 steps: n_in is a multiple
+// of 192 bits (24 ms x 8 kbit/s; the FIC's 768), followed by the six tail steps.
+//   dec:    32-bit decision words [chunk of 24 steps][64]: the word of the lane with basis coordinates A is stored
+//           at index A; the tags of the chunk's i-th group of six steps sit at bits 2 + 6 i .. 7 + 6 i.  The last
+//           word holds the tail group alone.
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
-//   out:    n_in/8 bytes.  nsteps (= n_in + 6, a multiple of 6), n_in (a multiple of 32) and all pointers are wave-uniform.
-//   xs:     the wave's staging buffer in LDS: [2 blocks][2 words][32 dwords]
+//   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
+//   xs:     the wave's staging buffer in LDS: [2 blocks][64 dwords]
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs)
 {
     const int lane = threadIdx.x & 63;
-    int sk[6], ss[6];
+    int sk[6];
 #pragma unroll
     for (int ph = 0; ph < 6; ++ph) {
         int st = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) st |= lane_coord(lane, (i + ph) % 6) << i;
-        int u = st & 1, o = conv_out0(st), kg = 0, sg = 0;
+        int u = st & 1, o = conv_out0(st), kg = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int neg = ((o >> (3 - j)) & 1) ^ u;
             kg |= (neg ? 0xC0 : 0x40) << (8 * j);          // -+64
-            sg |= (neg ? 0x40 : 0xC0) << (8 * j);
         }
-        sk[ph] = kg; ss[ph] = sg;
+        sk[ph] = kg;
     }
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
     int pm = lane == 0 ? 0 : PM_INIT * 64;
-    const int G = nsteps / 6, nwords = (G + 4) / 5;              // groups of six steps, decision words
-    // Soft-bit pipeline, three blocks of 60 steps deep: the depuncturing words of block b+2 and
+    const int nblk = nsteps / VIT_BLK, nwords = 2 * nblk + 1;    // full blocks of two chunks; decision words incl. the tail's
+    // Soft-bit pipeline, three blocks of 48 steps deep: the depuncturing words of block b+2 and
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
-    const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 60..63 fetch nothing
-    const int xslot = lane < 30 ? lane : (lane < VIT_BLK ? lane + 2 : 30 + (lane & 1));   // word 1 starts 128 bytes in (16-byte aligned reads)
-    const uint32_t xs_addr = (uint32_t)(uintptr_t)xs;            // LDS byte address (the low 32 bits of a shared pointer)
+    const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 48..63 fetch nothing
+    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);   // LDS byte address (the low 32 bits of a shared pointer)
     int xnext = gather_step(src, step_word(info, tl, nsteps));
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
-    const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
-    for (int blk = 0; blk < nblk; ++blk) {
-        int *xb = xs + (blk & 1) * 64;
-        xb[xslot] = xnext;                                       // lanes 60..63 write padding
+    for (int blk = 0; blk <= nblk; ++blk) {
+        xs[(blk & 1) * 64 + lane] = xnext;                       // lanes 48..63 write padding
         xnext = gather_step(src, wnext);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int w = 2 * blk + half;
-            const int ng = min(5, G - 5 * w);
-            if (ng <= 0) break;
-            uint32_t bits = 0;
-            const uint32_t va = xs_addr + (uint32_t)((blk & 1) * 256 + half * 128);
-            if (ng == 5) acs30(pm, sk, ss, va, lane_x32, bits);
-            else {
-                for (int gi = 0; gi < ng; ++gi) acs6(pm, sk, ss, va + 24u * gi, lane_x32, bits);
-                bits >>= 6 * (5 - ng);
-            }
-            dec[w * 64 + coordA] = bits;
+        const uint32_t va = va0 + (uint32_t)((blk & 1) * 256);
+        uint32_t bits = 0;
+        if (blk == nblk) {                                       // the six tail steps
+            acs6(pm, sk, va, lane_x32, bits);
+            dec[(nwords - 1) * 64 + coordA] = bits >> 24;
+            break;
         }
+        acs24(pm, sk, va, lane_x32, bits);
+        dec[(2 * blk) * 64 + coordA] = bits >> 6;
+        bits = 0;
+        acs24(pm, sk, va + 96u, lane_x32, bits);
+        dec[(2 * blk + 1) * 64 + coordA] = bits >> 6;
     }
     // ---- traceback on the scalar unit, in basis coordinates, from state 0, six steps per look-up: the position A
     // at the end of a group IS the group's six decoded bits (bit q = step 6 g + q), and the position six steps
-    // earlier is A ^ ~tags.  The last group is the tail.  Output words (32 steps) are assembled in a 64-bit shift
-    // register, earliest step on top.
+    // earlier is A ^ ~tags.  Only the low six bits of A matter (v_readlane and the bit reversal ignore the rest), so
+    // the tags are neither masked nor is the complement trimmed.  Four chunk words = 96 steps = three output words per
+    // iteration, fully unrolled; the next four words are loaded while these are walked.
     uint32_t A = 0;
-    uint64_t acc = 0;
-    int cnt = 0, ow = n_in >> 5;
+    {                                                            // the tail group: no output
+        const uint32_t word = dec[(nwords - 1) * 64 + lane];
+        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)word, 0) >> 2));
+    }
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
-    for (int w = nwords - 1; w >= 0; --w) {
-        const uint32_t word = dec[w * 64 + lane];
-        const int ng = min(5, G - 5 * w);
-        for (int gi = ng - 1; gi >= 0; --gi) {
-            const uint32_t h = ((uint32_t)__builtin_amdgcn_readlane((int)word, (int)A) >> (2 + 6 * gi)) & 63u;
-            if (5 * w + gi < G - 1) {
-                acc = (acc >> 6) | ((uint64_t)(__builtin_bitreverse32(A) >> 26) << 58);
-                cnt += 6;
-                if (cnt >= 32) {
-                    const uint32_t o = (uint32_t)(acc >> (64 - cnt));
-                    --ow;
-                    if (lane == 0) out32[ow] = __builtin_bswap32(o ^ prbs32[ow]);
-                    cnt -= 32;
-                }
+    const int nb96 = nblk >> 1;                                  // n_in is a multiple of 192
+    uint32_t wn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wn[k] = dec[((nb96 - 1) * 4 + k) * 64 + lane];
+    for (int b = nb96 - 1; b >= 0; --b) {
+        uint32_t wd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wd[k] = wn[k];
+        if (b > 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wn[k] = dec[((b - 1) * 4 + k) * 64 + lane];
+        }
+        uint32_t o[3] = {0u, 0u, 0u};                            // o[k]: step 96 b + 32 k + j at bit 31 - j
+#pragma unroll
+        for (int grp = 15; grp >= 0; --grp) {
+            const uint32_t rev = __builtin_bitreverse32(A) >> 26;             // step 6 grp + q at bit 5 - q
+            const int f = 6 * grp, k = f >> 5, off = f & 31;
+            if (off + 6 <= 32) o[k] |= rev << (26 - off);
+            else {
+                const int n1 = off + 6 - 32;                                  // bits that spill into the next word
+                o[k] |= rev >> n1;
+                o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
             }
-            A ^= ~h & 63u;
+            A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (2 + 6 * (grp & 3))));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out32[3 * b + k] = __builtin_bswap32(o[k] ^ prbs32[3 * b + k]);
         }
     }
 }
@@ -798,7 +808,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     if (wi >= n_cw) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][128];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
-    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * (((nsteps / 6 + 4) / 5) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave]);
+    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave]);
 }
 
 // stage-level FFT: one workgroup per vector, natural order in and out
