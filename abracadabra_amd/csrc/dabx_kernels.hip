@@ -670,17 +670,82 @@ __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int la
 #undef DABX_ACS_OPS
 
 constexpr int VIT_BLK = 48;          // trellis steps per soft-bit fetch block (lanes 0..47 fetch one step each) = two chunks
+constexpr int VIT_RING = 16;         // decision words (24 steps each) a wave keeps in LDS: 4 KB
+constexpr int VIT_UNIT = 8;          // words decoded (or, without a merge, spilled) at a time: 192 steps = 6 output words
 
-// Decode one terminated codeword with the calling wave.  Every DAB codeword has 48 k + 6 steps: n_in is a multiple
+// Walk 96 steps (the four decision words wd[0..3], lane = basis coordinate) backwards from position A; writes the
+// three output words of block b96.  The position A at the end of a group IS the group's six decoded bits
+// (bit q = step 6 g + q), the position six steps earlier is A ^ ~tags.  Only the low six bits of A matter
+// (v_readlane and the bit reversal ignore the rest), so neither the tags are masked nor the complement trimmed.
+__device__ __forceinline__ uint32_t walk96(const uint32_t wd[4], uint32_t A, uint32_t *out32, const uint32_t *__restrict__ prbs32, int b96,
+                                           int lane)
+{
+    uint32_t o[3] = {0u, 0u, 0u};                                // o[k]: step 96 b + 32 k + j at bit 31 - j
+#pragma unroll
+    for (int grp = 15; grp >= 0; --grp) {
+        const uint32_t rev = __builtin_bitreverse32(A) >> 26;                 // step 6 grp + q at bit 5 - q
+        const int f = 6 * grp, k = f >> 5, off = f & 31;
+        if (off + 6 <= 32) o[k] |= rev << (26 - off);
+        else {
+            const int n1 = off + 6 - 32;                                      // bits that spill into the next word
+            o[k] |= rev >> n1;
+            o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
+        }
+        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (2 + 6 * (grp & 3))));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out32[3 * b96 + k] = __builtin_bswap32(o[k] ^ prbs32[3 * b96 + k]);
+    }
+    return A;
+}
+
+// Decode the words [w_lo, w_hi) (multiples of 4) backwards from position A at the end of word w_hi - 1.  Words from
+// w_ring on are in the wave's LDS ring, older ones (spilled because no merge was found in time) in global scratch.
+__device__ __forceinline__ void trace_words(const uint32_t *ring, const uint32_t *dec, int w_ring, int w_lo, int w_hi, uint32_t A,
+                                            uint32_t *out32, const uint32_t *__restrict__ prbs32, int lane)
+{
+    for (int w = w_hi - 4; w >= w_lo; w -= 4) {
+        uint32_t wd[4];
+        if (w >= w_ring) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wd[k] = ring[((w + k) & (VIT_RING - 1)) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wd[k] = dec[(w + k) * 64 + lane];
+        }
+        A = walk96(wd, A, out32, prbs32, w >> 2, lane);
+    }
+}
+
+// Have the 64 survivors at the end of word w_hi - 1 merged by the start of word B?  Every lane walks its own
+// survivor back through the ring (a gather per six steps); if all arrive at one position, every path through any
+// later trellis state passes through it: the words before B can be decoded now, exactly.
+__device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi, int B, int coordA, uint32_t &O)
+{
+    uint32_t P = (uint32_t)coordA;
+    for (int w = w_hi - 1; w >= B; --w) {
+        const uint32_t *row = ring + (w & (VIT_RING - 1)) * 64;
+#pragma unroll
+        for (int gi = 3; gi >= 0; --gi) P = ~(P ^ (row[P & 63u] >> (2 + 6 * gi)));
+    }
+    P &= 63u;
+    O = (uint32_t)__builtin_amdgcn_readfirstlane((int)P);
+    return __builtin_amdgcn_ballot_w64(P != O) == 0;
+}
+
+// Decode one terminated codeword with the calling wave.  Every DAB codeword has 192 k + 6 steps: n_in is a multiple
 // of 192 bits (24 ms x 8 kbit/s; the FIC's 768), followed by the six tail steps.
-//   dec:    32-bit decision words [chunk of 24 steps][64]: the word of the lane with basis coordinates A is stored
-//           at index A; the tags of the chunk's i-th group of six steps sit at bits 2 + 6 i .. 7 + 6 i.  The last
-//           word holds the tail group alone.
+//   ring:   the wave's VIT_RING x 64 decision words in LDS: word w (the 24 steps of chunk w) of the lane with basis
+//           coordinates A at [(w mod VIT_RING) * 64 + A]; the tags of the chunk's i-th group of six steps sit at
+//           bits 2 + 6 i .. 7 + 6 i
+//   dec:    the codeword's block of global scratch, same layout without the modulus: touched only when the
+//           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's staging buffer in LDS: [2 blocks][64 dwords]
+//   xs:     the wave's soft-value staging buffer in LDS: [2 blocks][64 dwords]
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
-                             const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs)
+                             const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
     const int lane = threadIdx.x & 63;
     int sk[6];
@@ -700,7 +765,9 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
     int pm = lane == 0 ? 0 : PM_INIT * 64;
-    const int nblk = nsteps / VIT_BLK, nwords = 2 * nblk + 1;    // full blocks of two chunks; decision words incl. the tail's
+    const int nblk = nsteps / VIT_BLK;                           // full blocks of two chunks (even); the tail follows
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    int w_dec = 0, w_ring = 0;                                   // first word not yet decoded / first word still in the ring
     // Soft-bit pipeline, three blocks of 48 steps deep: the depuncturing words of block b+2 and
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
@@ -708,79 +775,56 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);   // LDS byte address (the low 32 bits of a shared pointer)
     int xnext = gather_step(src, step_word(info, tl, nsteps));
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
+    uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
         xs[(blk & 1) * 64 + lane] = xnext;                       // lanes 48..63 write padding
         xnext = gather_step(src, wnext);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
         const uint32_t va = va0 + (uint32_t)((blk & 1) * 256);
         uint32_t bits = 0;
-        if (blk == nblk) {                                       // the six tail steps
+        if (blk == nblk) {                                       // the six tail steps: no output, from state 0 (lane 0)
             acs6(pm, sk, va, lane_x32, bits);
-            dec[(nwords - 1) * 64 + coordA] = bits >> 24;
+            A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
             break;
         }
         acs24(pm, sk, va, lane_x32, bits);
-        dec[(2 * blk) * 64 + coordA] = bits >> 6;
+        ring[((2 * blk) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
         bits = 0;
         acs24(pm, sk, va + 96u, lane_x32, bits);
-        dec[(2 * blk + 1) * 64 + coordA] = bits >> 6;
-    }
-    // ---- traceback on the scalar unit, in basis coordinates, from state 0, six steps per look-up: the position A
-    // at the end of a group IS the group's six decoded bits (bit q = step 6 g + q), and the position six steps
-    // earlier is A ^ ~tags.  Only the low six bits of A matter (v_readlane and the bit reversal ignore the rest), so
-    // the tags are neither masked nor is the complement trimmed.  Four chunk words = 96 steps = three output words per
-    // iteration, fully unrolled; the next four words are loaded while these are walked.
-    uint32_t A = 0;
-    {                                                            // the tail group: no output
-        const uint32_t word = dec[(nwords - 1) * 64 + lane];
-        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)word, 0) >> 2));
-    }
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
-    const int nb96 = nblk >> 1;                                  // n_in is a multiple of 192
-    uint32_t wn[4];
+        ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
+        // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
+        const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
+        if (pend >= VIT_UNIT + 4 && !(pend & 1)) {               // 96, 144, 192 steps after the unit's end
+            const int B = w_ring + VIT_UNIT;
+            uint32_t O;
+            if (survivors_merged(ring, w_hi, B, coordA, O)) {
+                trace_words(ring, dec, w_ring, w_dec, B, O, out32, prbs32, lane);
+                w_dec = w_ring = B;
+            } else if (pend == VIT_RING) {                       // no merge and the ring is full: the unit goes to global scratch
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wn[k] = dec[((nb96 - 1) * 4 + k) * 64 + lane];
-    for (int b = nb96 - 1; b >= 0; --b) {
-        uint32_t wd[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wd[k] = wn[k];
-        if (b > 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wn[k] = dec[((b - 1) * 4 + k) * 64 + lane];
-        }
-        uint32_t o[3] = {0u, 0u, 0u};                            // o[k]: step 96 b + 32 k + j at bit 31 - j
-#pragma unroll
-        for (int grp = 15; grp >= 0; --grp) {
-            const uint32_t rev = __builtin_bitreverse32(A) >> 26;             // step 6 grp + q at bit 5 - q
-            const int f = 6 * grp, k = f >> 5, off = f & 31;
-            if (off + 6 <= 32) o[k] |= rev << (26 - off);
-            else {
-                const int n1 = off + 6 - 32;                                  // bits that spill into the next word
-                o[k] |= rev >> n1;
-                o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
+                for (int k = 0; k < VIT_UNIT; ++k) dec[(w_ring + k) * 64 + lane] = ring[((w_ring + k) & (VIT_RING - 1)) * 64 + lane];
+                w_ring = B;
             }
-            A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (2 + 6 * (grp & 3))));
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) out32[3 * b + k] = __builtin_bswap32(o[k] ^ prbs32[3 * b + k]);
         }
     }
+    trace_words(ring, dec, w_ring, w_dec, 2 * nblk, A, out32, prbs32, lane);
 }
 
 }  // namespace
 
 // One wave per codeword (work item): FIC codeword c (0..3) of (stream, frame) when sub < 0, else MSC
-// sub-channel `sub` of CIF c.  Decisions go to the item's block of dec_scratch in global memory rather than
-// LDS: with no LDS per wave eight waves per SIMD are resident, which is what hides the ACS dependency chain
-// (measured: 3 waves/SIMD with 12.5 KB of LDS decisions each took 1.27x as long).
+// sub-channel `sub` of CIF c.  Decisions live in a 4 KB ring of LDS per wave (eight waves per SIMD stay resident)
+// and are decoded as soon as the survivors have merged; the item's block of dec_scratch in global memory is the
+// fallback for input whose survivors do not merge.
 __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__restrict__ work, int n_work)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][128];
+    __shared__ uint32_t ring_all[4][VIT_RING * 64];
     int *xs = xs_all[wave];
+    uint32_t *ring = ring_all[wave];
     const DevWork w = work[wi];
     const DevState &st = C.state[w.stream];
     if (st.acq_fail) return;
@@ -788,14 +832,14 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     if (w.sub < 0) {
         VitSrc src = {C.fic_soft + ((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304, 0, -1};
         uint8_t *out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
-        viterbi_wave(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out, xs);
+        viterbi_wave(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out, xs, ring);
     } else {
         const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
         const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
         if (r < 0) return;                           // time de-interleaver still filling (k_finish flags it)
         VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + (sc.start_bit >> 4), r, C.ti_slots - 1};
         uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
-        viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out, xs);
+        viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out, xs, ring);
     }
 }
 
@@ -807,8 +851,9 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][128];
+    __shared__ uint32_t ring_all[4][VIT_RING * 64];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
-    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave]);
+    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
 }
 
 // stage-level FFT: one workgroup per vector, natural order in and out
