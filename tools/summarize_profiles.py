@@ -41,6 +41,11 @@ def main(tag, streams=256, frames=8):
             fetch, write = d["FETCH_SIZE"]["max"], d["WRITE_SIZE"]["max"]        # steady-state dispatch
             traffic["kernels"][k] = {"fetch_size_kib_raw": fetch, "write_size_kib": write,
                                      "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
+            for c, key in (("SQ_INSTS_VALU", "insts_valu_per_launch"), ("SQ_INSTS_SALU", "insts_salu_per_launch"),
+                           ("SQ_INSTS_LDS", "insts_lds_per_launch"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"),
+                           ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles")):
+                if c in d:
+                    traffic["kernels"][k][key] = int(d[c]["max"])
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     for k, v in traffic["kernels"].items():
         print(k[:40], v)
