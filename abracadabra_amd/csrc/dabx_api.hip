@@ -602,7 +602,7 @@ int dabx_get_state(dabx_ctx *c, int s, dabx_stream_state_t *st)
     GETTER_PROLOGUE
     if (!st) return DABX_E_ARG;
     const auto &sh = c->streams[s];
-    *st = {sh.st.pos, sh.st.inc, sh.st.locked, sh.st.cif, sh.st.bad, 0, sh.wr};
+    *st = {sh.st.pos, sh.st.inc, sh.st.locked, sh.st.cif, sh.st.bad, sh.st.slope, sh.wr};
     return DABX_OK;
 }
 

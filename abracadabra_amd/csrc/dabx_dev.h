@@ -24,6 +24,8 @@ struct DevState {
     int32_t locked;
     int32_t bad;        // consecutive frames without PRS
     int32_t acq_fail;   // set by k_null_search for the current step only
+    int32_t slope;      // tracked sampling-clock drift of the recording: samples per frame, Q16
+    int32_t pad;
 };
 
 struct DevSync {        // same layout as dabx_sync_rec_t

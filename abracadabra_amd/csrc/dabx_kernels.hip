@@ -25,6 +25,10 @@ constexpr int NSYM = 76, SYMBITS = 3072, NCAR = 1536;
 constexpr int FICBITS = 9216, CIFBITS = 55296;
 constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 17, PM_INIT = -1000000;
 constexpr float LOCK_THR = 48.0f;
+constexpr int EARLY_SPAN = 400;            // the first path may lead the strongest one by up to this many samples ...
+constexpr float EARLY_THR = 0.125f;        // ... if it carries at least this fraction of its power (-9 dB)
+constexpr int RESYNC_THR = 32;             // PRS further than this from where the window expected it: second pass
+constexpr int SLOPE_MAX = 60 << 16;        // sampling-clock tracker: |drift| <= 60 samples per frame (~300 ppm), Q16
 constexpr int TI_SEG = CIFBITS / 16;   // bytes per residue class in a residue-major MSC row
 
 struct cf { float r, i; };
@@ -242,17 +246,20 @@ __global__ __launch_bounds__(256) void k_null_search(DevCtx C)
     const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
     const int64_t from = wrap(st.pos, C.ring_len);
     for (int b = t; b < NS_BLOCKS + NS_WIN; b += 256) {
+        // 64 x the variance of the block (exact integers): a DC offset of the recording must not fill the null symbol
         uint64_t e = 0;
+        int64_t si = 0, sq = 0;
         int64_t idx = from + 64 * (int64_t)b;
         idx = idx >= C.ring_len ? idx - C.ring_len : idx;
         idx = idx >= C.ring_len ? idx - C.ring_len : idx;
         for (int n = 0; n < 64; ++n) {
             int i, q;
             sample<FMT>(ring, idx, i, q);
-            e += (uint64_t)(i * i + q * q);
+            e += (uint64_t)((int64_t)i * i + (int64_t)q * q);
+            si += i; sq += q;
             if (++idx >= C.ring_len) idx -= C.ring_len;
         }
-        E[b] = e;
+        E[b] = 64 * e - (uint64_t)(si * si) - (uint64_t)(sq * sq);
     }
     __syncthreads();
     uint64_t tot = 0, best = ~0ULL;
@@ -309,11 +316,21 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
     __shared__ int32_t sh_inc;
     __shared__ float pk_v[4];
     __shared__ int pk_i[4];
+    __shared__ int64_t sh_m;
+    __shared__ int sh_d[4];
     const DevTables &T = C.tab;
     const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
     const int wide = !st.locked;
-    const int64_t pos_f = st.pos + (int64_t)f * TF;
+    // frame f is expected where the tracked sampling-clock drift puts it (no drift is known while acquiring)
+    int64_t pos_f = st.pos + (int64_t)f * TF + (wide ? 0 : (((int64_t)f * st.slope) >> 16));
+    Twiddles tw;
+    load_twiddles(tw, T.W, t);
+    cf v[8];
+    int32_t inc = 0;
 
+    // A pass at the predicted frame start and, when the PRS turns out to sit more than RESYNC_THR samples from where
+    // the window expected it, a second pass at the corrected position (the guard correlation must look at guards).
+    for (int pass = 0; pass < 2; ++pass) {
     // 1. guard-interval correlation over the PRS and the three FIC symbols
     int64_t cre = 0, cim = 0, en = 0, es = 0;
     {
@@ -363,13 +380,10 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         sh_inc = inc;
     }
     __syncthreads();
-    int32_t inc = sh_inc;
+    inc = sh_inc;
 
-    Twiddles tw;
-    load_twiddles(tw, T.W, t);
     const int64_t w0 = pos_f + TNULL + TG - BACKOFF;
     const int64_t w0i = wrap(w0, C.ring_len);
-    cf v[8];
     load_window<FMT>(v, T, ring, C.ring_len, w0i, 0u, inc, t);
     fft2048(v, buf, t, tw);
     int m_best = 0;
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         fft2048(v, buf, t, tw);
     }
     // optional signal spectrum of the last frame (reference: dabsdrSpectrumCBFunc_t, dabsdr.h:393):
-    // linear power of the un-normalised 2048-point FFT, natural bin order
+    // linear power of the un-normalised 2048-point FFT, natural bin order (a second pass overwrites the first)
     if (C.spectrum && f == n_frames - 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -441,10 +455,30 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
     }
     if ((t & 63) == 0) { pk_v[t >> 6] = peak; pk_i[t >> 6] = pidx; }
     __syncthreads();
+    for (int w = 0; w < 4; ++w)                                  // every thread: the block's peak
+        if (pk_v[w] > peak || (pk_v[w] == peak && pk_i[w] < pidx)) { peak = pk_v[w]; pidx = pk_i[w]; }
+    // the FFT window follows the FIRST significant path, not the strongest: among the taps up to EARLY_SPAN samples
+    // before the peak the earliest one with at least EARLY_THR of the peak's power wins
+    {
+        const float thr = peak * EARLY_THR;
+        int dmax = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = (pidx - T.bin_of_pos[8 * t + e]) & 2047;
+            const float a = v[e].r * v[e].r, b = v[e].i * v[e].i, m2 = a + b;
+            if (d != 0 && d <= EARLY_SPAN && m2 >= thr && d > dmax) dmax = d;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) dmax = max(dmax, __shfl_xor(dmax, d, 64));
+        __syncthreads();
+        if ((t & 63) == 0) sh_d[t >> 6] = dmax;
+        __syncthreads();
+        dmax = max(max(sh_d[0], sh_d[1]), max(sh_d[2], sh_d[3]));
+        pidx = (pidx - dmax) & 2047;
+    }
     if (t == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (pk_v[w] > peak || (pk_v[w] == peak && pk_i[w] < pidx)) { peak = pk_v[w]; pidx = pk_i[w]; }
         int delta = pidx >= 1024 ? pidx - 2048 : pidx;
+        sh_m = (int64_t)delta - BACKOFF;                         // how far the PRS sits from where the window expected it
         DevSync r;
         r.t_sym0 = w0 + delta - BACKOFF;
         r.inc = inc;
@@ -455,6 +489,12 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         r.e_null = en; r.e_sig = es;
         rec = r;
     }
+    __syncthreads();
+    const int64_t m = sh_m;
+    if (pass == 1 || (m <= RESYNC_THR && m >= -RESYNC_THR)) break;
+    pos_f += m;
+    __syncthreads();
+    }   // pass
     // optional spectrum of the null symbol (TII carriers; reference: DABSDR_SPECT_NULL / dabsdrNtfTii_t):
     // 2048 samples centred in the 2656-sample null symbol, de-rotated like the PRS window
     if (C.null_spectrum && f == n_frames - 1) {
@@ -897,9 +937,28 @@ __global__ __launch_bounds__(256) void k_finish(DevCtx C, int n_frames)
         }
         const int wide = !st.locked;
         int nbad = st.bad;
-        for (int f = 0; f < n_frames; ++f) nbad = (C.sync[(size_t)s * C.max_frames + f].flags & 1) ? 0 : nbad + 1;
+        // sampling-clock tracker (first order, gain 1/4): timing error of the good frames against their prediction
+        const int32_t slope0 = wide ? 0 : st.slope;
+        int64_t e_first = 0, e_last = 0;
+        int f_first = -1, f_last = -1;
+        for (int f = 0; f < n_frames; ++f) {
+            const DevSync &r = C.sync[(size_t)s * C.max_frames + f];
+            nbad = (r.flags & 1) ? 0 : nbad + 1;
+            if (r.flags & 1) {
+                const int64_t e = r.t_sym0 + BACKOFF - TG - TNULL - (st.pos + (int64_t)f * TF + (((int64_t)f * slope0) >> 16));
+                if (f_first < 0) { f_first = f; e_first = e; }
+                f_last = f; e_last = e;
+            }
+        }
+        // tracking: the error of frame f has built up over f + 1 frames since the last measured frame start;
+        // acquisition: the drift between two good frames of the step
+        int32_t sl = slope0;
+        if (!wide && f_last >= 0) sl += (int32_t)(((e_last * 65536) / (f_last + 1)) / 4);
+        else if (wide && f_last > f_first) sl = (int32_t)(((e_last - e_first) * 65536) / (f_last - f_first));
+        sl = min(max(sl, -SLOPE_MAX), SLOPE_MAX);
         const DevSync &last = C.sync[(size_t)s * C.max_frames + n_frames - 1];
-        st.pos = last.t_sym0 + BACKOFF - TG - TNULL + TF;
+        st.slope = sl;
+        st.pos = last.t_sym0 + BACKOFF - TG - TNULL + TF + (sl >> 16);
         st.inc = last.inc;
         st.cif += 4 * (int64_t)n_frames;
         st.bad = nbad;

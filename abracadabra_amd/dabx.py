@@ -41,7 +41,7 @@ class SubCh(C.Structure):
 
 class StreamState(C.Structure):
     _fields_ = [("pos", C.c_int64), ("inc", C.c_int32), ("locked", C.c_int32), ("cif", C.c_int64),
-                ("bad", C.c_int32), ("reserved", C.c_int32), ("wr", C.c_int64)]
+                ("bad", C.c_int32), ("slope_q16", C.c_int32), ("wr", C.c_int64)]
 
 
 class RawFileInfo(C.Structure):
@@ -235,7 +235,7 @@ class Context:
     def state(self, stream):
         st = StreamState()
         _chk(self.L.dabx_get_state(self.h, stream, C.byref(st)))
-        return dict(pos=st.pos, inc=st.inc, locked=st.locked, cif=st.cif, bad=st.bad, wr=st.wr)
+        return dict(pos=st.pos, inc=st.inc, locked=st.locked, cif=st.cif, bad=st.bad, wr=st.wr, slope=st.slope_q16)
 
     def fic_soft(self, stream):
         a = np.zeros((self.last_frames, FIC_SOFT_BITS), dtype=np.int8)

@@ -75,7 +75,7 @@ typedef struct {
     int32_t locked;               /* 0 searching, 1 tracking                              */
     int64_t cif;                  /* CIFs demodulated since lock                          */
     int32_t bad;                  /* consecutive frames without PRS                       */
-    int32_t reserved;
+    int32_t slope_q16;            /* tracked sampling-clock drift of the recording: samples per frame, Q16 */
     int64_t wr;                   /* samples pushed so far (host side)                    */
 } dabx_stream_state_t;
 

@@ -179,9 +179,9 @@ class Stream:
         return out
 
     def state(self):
-        st = np.zeros(6, dtype=np.int64)
+        st = np.zeros(7, dtype=np.int64)
         self.L.orx_get_state(self.h, st.ctypes.data)
-        return dict(pos=int(st[0]), inc=int(st[1]), locked=int(st[2]), cif=int(st[3]), bad=int(st[4]), wr=int(st[5]))
+        return dict(pos=int(st[0]), inc=int(st[1]), locked=int(st[2]), cif=int(st[3]), bad=int(st[4]), wr=int(st[5]), slope=int(st[6]))
 
     def process(self, n_frames, want_soft=True):
         out = dict(

@@ -27,6 +27,9 @@
 #define SOFT_EXP 17         /* soft-bit scale exponent, see demap()                 */
 #define PM_INIT (-1000000)  /* path metric of states other than 0 at trellis start  */
 #define LOCK_THR 48.0f
+#define EARLY_SPAN 400      /* the first path may lead the strongest one by up to this many samples ...   */
+#define EARLY_THR 0.125f    /* ... if it carries at least this fraction of its power (-9 dB)               */
+#define SLOPE_MAX (60 << 16)/* sampling-clock tracker: |drift| <= 60 samples per frame (~300 ppm), Q16      */
 
 /* ------------------------------------------------------------------ tables */
 typedef struct {
@@ -218,6 +221,7 @@ typedef struct {
     int64_t pos;                /* estimated start of the next frame's null symbol */
     int32_t inc;                /* carrier offset, 2^-32 turn per sample */
     int32_t locked, bad;
+    int32_t slope;              /* sampling-clock drift of the recording, samples per frame in Q16 (tracked) */
     int64_t cif;                /* CIFs demodulated since lock */
     int n_subch, msc_bytes;
     subch_t sub[64];
@@ -293,7 +297,7 @@ void orx_get_spectrum(const orx_t *s, float *out) { memcpy(out, s->spectrum, siz
 void orx_get_null_spectrum(const orx_t *s, float *out) { memcpy(out, s->null_spectrum, sizeof s->null_spectrum); }
 void orx_get_state(const orx_t *s, int64_t *st)
 {
-    st[0] = s->pos; st[1] = s->inc; st[2] = s->locked; st[3] = s->cif; st[4] = s->bad; st[5] = s->wr;
+    st[0] = s->pos; st[1] = s->inc; st[2] = s->locked; st[3] = s->cif; st[4] = s->bad; st[5] = s->wr; st[6] = s->slope;
 }
 
 static inline void sample(const orx_t *s, int64_t n, int32_t *i, int32_t *q)
@@ -312,13 +316,17 @@ static int null_search(const orx_t *s, int64_t from, int64_t *null_start)
     uint64_t E[NS_BLOCKS + NS_WIN];
     uint64_t tot = 0;
     for (int b = 0; b < NS_BLOCKS + NS_WIN; b++) {
+        /* 64 x the variance of the block: a DC offset of the recording (RTL-SDR dongles have one) must not fill
+         * the null symbol.  Exact integers: 64 sum |x|^2 - |sum x|^2 */
         uint64_t e = 0;
+        int64_t si = 0, sq = 0;
         for (int n = 0; n < 64; n++) {
             int32_t i, q; sample(s, from + 64 * (int64_t)b + n, &i, &q);
-            e += (uint64_t)(i * i + q * q);
+            e += (uint64_t)((int64_t)i * i + (int64_t)q * q);
+            si += i; sq += q;
         }
-        E[b] = e;
-        if (b < NS_BLOCKS) tot += e;
+        E[b] = 64 * e - (uint64_t)(si * si) - (uint64_t)(sq * sq);
+        if (b < NS_BLOCKS) tot += E[b];
     }
     uint64_t best = ~0ULL; int bb = 0;
     for (int b = 0; b < NS_BLOCKS; b++) {
@@ -355,7 +363,20 @@ static void load_window(const orx_t *s, int64_t w0, int64_t ref, int32_t inc, fl
     }
 }
 
+static void sync_pass(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec, float *spectrum, float *null_spectrum);
+
+/* One frame: a pass at the predicted frame start and, when the PRS turns out to sit more than RESYNC_THR samples away
+ * from where the window expected it (acquisition of a recording with a sampling-clock error, several frames per step),
+ * a second pass at the corrected position, so that the guard-interval correlation looks at guard intervals. */
+#define RESYNC_THR 32
 static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec, float *spectrum, float *null_spectrum)
+{
+    sync_pass(s, pos_f, inc0, wide, rec, spectrum, null_spectrum);
+    int64_t m = rec->t_sym0 - (pos_f + DAB_TNULL + DAB_TG - BACKOFF);
+    if (m > RESYNC_THR || m < -RESYNC_THR) sync_pass(s, pos_f + m, inc0, wide, rec, spectrum, null_spectrum);
+}
+
+static void sync_pass(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec, float *spectrum, float *null_spectrum)
 {
     /* 1. guard-interval correlation over PRS + 3 FIC symbols (exact integers) */
     int64_t cre = 0, cim = 0;
@@ -440,6 +461,20 @@ static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, or
         part[t] = acc;
     }
     float total = reduce256(part);
+    /* the FFT window follows the FIRST significant path, not the strongest: a weaker path that arrives earlier would
+     * otherwise leak its next symbol into the window.  Among the taps up to EARLY_SPAN samples before the peak the
+     * earliest one with at least EARLY_THR of the peak's power wins. */
+    {
+        float thr = peak * EARLY_THR;
+        int dmax = 0;
+        for (int p = 0; p < NFFT; p++) {
+            int d = (pidx - T.bin_of_pos[p]) & 2047;
+            if (d == 0 || d > EARLY_SPAN) continue;
+            float a = hr[p] * hr[p], b = hi[p] * hi[p], m2 = a + b;
+            if (m2 >= thr && d > dmax) dmax = d;
+        }
+        pidx = (pidx - dmax) & 2047;
+    }
     int delta = pidx >= 1024 ? pidx - 2048 : pidx;
     rec->t_sym0 = w0 + delta - BACKOFF;
     rec->inc = inc;
@@ -464,6 +499,9 @@ static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, or
 static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *fic)
 {
     float pr[NFFT], pi[NFFT], xr[NFFT], xi[NFFT], yr[NFFT], yi[NFFT], part[256];
+    /* The symbol windows of a frame keep their nominal spacing: moving a window by a whole sample between two symbols
+     * would put a phase step of 2 pi k / 2048 into the differential product.  A sampling-clock error of 100 ppm moves
+     * the last symbol by 20 samples against the first, which the BACKOFF of the window inside the guard absorbs. */
     for (int l = 0; l < DAB_NSYM; l++) {
         load_window(s, rec->t_sym0 + (int64_t)l * DAB_TS, rec->t_sym0, rec->inc, xr, xi);
         fft_pos(xr, xi);
@@ -653,8 +691,14 @@ int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8
     int8_t *ficbuf = (int8_t *)malloc(DAB_FIC_BITS);
     orx_sync_t rec;
     int nbad = s->bad;
+    if (wide) s->slope = 0;
+    const int64_t pos0 = s->pos;
+    int64_t e_first = 0, e_last = 0;
+    int f_first = -1, f_last = -1;
     for (int f = 0; f < n_frames; f++) {
-        sync_frame(s, s->pos + (int64_t)f * DAB_TF, s->inc, wide, &rec, f == n_frames - 1 ? s->spectrum : NULL, f == n_frames - 1 ? s->null_spectrum : NULL);
+        /* frame f is expected where the tracked sampling-clock drift puts it */
+        const int64_t pos_f = pos0 + (int64_t)f * DAB_TF + (((int64_t)f * s->slope) >> 16);
+        sync_frame(s, pos_f, s->inc, wide, &rec, f == n_frames - 1 ? s->spectrum : NULL, f == n_frames - 1 ? s->null_spectrum : NULL);
         if (sync) sync[f] = rec;
         int64_t cif0 = s->cif + 4 * (int64_t)f;
         demod_frame(s, &rec, cif0, ficbuf);
@@ -686,8 +730,21 @@ int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8
             }
         }
         nbad = (rec.flags & 1) ? 0 : nbad + 1;
+        if (rec.flags & 1) {                                /* timing error of a good frame against its prediction */
+            int64_t e = rec.t_sym0 + BACKOFF - DAB_TG - DAB_TNULL - pos_f;
+            if (f_first < 0) { f_first = f; e_first = e; }
+            f_last = f; e_last = e;
+        }
         if (f == n_frames - 1) {
-            s->pos = rec.t_sym0 + BACKOFF - DAB_TG - DAB_TNULL + DAB_TF;
+            /* sampling-clock tracker (first order, gain 1/4).  Tracking: the error of frame f has built up over f + 1
+             * frames since the last measured frame start.  Acquisition: the drift between two good frames of the step. */
+            int32_t sl = s->slope;
+            if (!wide && f_last >= 0) sl += (int32_t)(((e_last * 65536) / (f_last + 1)) / 4);
+            else if (wide && f_last > f_first) sl = (int32_t)(((e_last - e_first) * 65536) / (f_last - f_first));
+            if (sl > SLOPE_MAX) sl = SLOPE_MAX;
+            if (sl < -SLOPE_MAX) sl = -SLOPE_MAX;
+            s->slope = sl;
+            s->pos = rec.t_sym0 + BACKOFF - DAB_TG - DAB_TNULL + DAB_TF + (sl >> 16);
             s->inc = rec.inc;
         }
     }

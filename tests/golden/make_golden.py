@@ -23,6 +23,9 @@ CASES = {
     "u8_18x48cu_snr15": dict(seed=101, eid=0x4001, n_frames=6, subch=ob.subch_layout(18, 64), delay=4321, snr_db=15.0, cfo_hz=-1875.5, fmt=0),
     "s16_mixed_profiles": dict(seed=102, eid=0x4002, n_frames=6, subch=[[0, 0, 3, 64], [48, 1, 4, 32], [100, 0, 1, 8], [200, 0, 2, 32], [300, 0, 4, 72]],
                                delay=150000, snr_db=12.0, cfo_hz=6100.25, fmt=1, rms=3000.0),
+    # a non-ideal channel: receiver clock 60 ppm slow, second path 150 samples late at -5 dB, DC offset
+    "u8_impaired_channel": dict(seed=104, eid=0x4004, n_frames=8, subch=ob.subch_layout(3, 64), delay=7000, snr_db=15.0, cfo_hz=2250.0, fmt=0,
+                                sco_ppm=-60.0, echo=(150, 5.0, 2.0), dc=(4.0, -3.0)),
 }
 
 

@@ -12,7 +12,7 @@ import pytest
 from oracle import binding as ob
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["u8_18x48cu_snr15", "s16_mixed_profiles"]
+CASES = ["u8_18x48cu_snr15", "s16_mixed_profiles", "u8_impaired_channel"]
 
 
 def _load(name):

@@ -68,7 +68,7 @@ def test_config3_256_ensembles_full_msc(gpu_ctx_factory):
                 assert np.array_equal(gf, o["fib"]) and np.array_equal(gok, o["fib_ok"])
                 assert np.array_equal(gv, o["msc_valid"]) and np.array_equal(gm[gv == 1], o["msc"][o["msc_valid"] == 1])
                 st, so = ctx.state(s), oracles[s].state()
-                assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"])
+                assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"], st["slope"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"], so["slope"])
 
 
 def _bench(extra, timeout=900):

@@ -62,7 +62,7 @@ def _run_pair(ctx, streams, steps, frames, subs):
             assert np.array_equal(gm[gv == 1], o["msc"][o["msc_valid"] == 1])
             st = ctx.state(s)
             so = orc.state()
-            assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"])
+            assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"], st["slope"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"], so["slope"])
             results.append((s, gf, gok, gm, gv))
     return results
 
@@ -317,6 +317,6 @@ def test_lock_loss_and_reacquisition_matches_oracle(gpu_ctx_factory):
         if o["rc"]:
             assert np.array_equal(gf, o["fib"])
         st, so = ctx.state(0), orc.state()
-        assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"])
+        assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"], st["slope"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"], so["slope"])
         locked.append(st["locked"])
     assert locked[0] == 1 and 0 in locked[1:] and locked[-1] == 1

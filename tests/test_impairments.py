@@ -1,0 +1,76 @@
+"""Non-ideal channels: sampling-clock offset of the recording, a second path inside the guard
+interval, DC offset.  The transmitter (oracle/dab_tx.c) applies them; the receiver has to track the clock drift over
+steps of 1, 8 and 32 frames, follow the FIRST path and ignore the DC offset.  CPU: the oracle alone; GPU: the HIP path,
+bit for bit equal to the oracle on every tap and every FIB CRC good."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+SUB = ob.subch_layout(2, 64)
+SCENARIOS = {
+    "clock_fast_100ppm": dict(sco_ppm=100.0),
+    "clock_slow_100ppm": dict(sco_ppm=-100.0),
+    "echo_late_weaker": dict(echo=(200, 6.0, 1.0)),
+    "echo_late_stronger": dict(echo=(150, -3.0, 2.0)),          # the first path is the weaker one: the window must follow it
+    "dc_offset": dict(dc=(6.0, -4.0)),
+    "everything": dict(sco_ppm=-100.0, dc=(5.0, 5.0), echo=(120, 4.0, 0.5), cfo_hz=1500.0),
+}
+
+
+def _signal(name, n_frames, seed=5):
+    kw = dict(snr_db=15.0)
+    kw.update(SCENARIOS[name])
+    return ob.tx_generate(seed=seed, n_frames=n_frames, subch=SUB, delay=3000, **kw)
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+@pytest.mark.parametrize("step", [1, 8, 32])
+def test_oracle_decodes_impaired_channel(name, step):
+    nf = 34 if step < 32 else 66
+    iq, fib, msc = _signal(name, nf)
+    o = ob.Stream(subch=SUB, ring_len=(nf + 2) * ob.TF, ti_slots=256)
+    o.push(iq)
+    done = 0
+    while done + step <= nf - 1:
+        r = o.process(step, want_soft=False)
+        assert r["rc"] == step
+        assert r["fib_ok"].all(), f"{name}: FIB CRC failures in frames {done}..{done + step - 1}"
+        assert np.array_equal(r["fib"], fib[done:done + step])
+        done += step
+    assert o.state()["locked"] == 1
+    if "sco_ppm" in SCENARIOS[name]:                      # the tracker found the drift: -ppm x 196608 samples per frame
+        want = -SCENARIOS[name]["sco_ppm"] * 1e-6 * ob.TF
+        assert abs(o.state()["slope"] / 65536.0 - want) < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("step", [1, 8, 32])
+def test_gpu_equals_oracle_on_impaired_channels(gpu_ctx_factory, step):
+    nf = 18 if step == 1 else (34 if step == 8 else 66)
+    names = list(SCENARIOS)
+    ctx = gpu_ctx_factory(n_streams=len(names), fmt=0, ring_frames=nf + 2, max_frames=step)
+    oracles, truth = [], []
+    for s, name in enumerate(names):
+        iq, fib, msc = _signal(name, nf, seed=40 + s)
+        ctx.set_subchannels(s, SUB)
+        ctx.push(s, iq)
+        o = ob.Stream(subch=SUB, ring_len=(nf + 2) * ob.TF, ti_slots=256)
+        o.push(iq)
+        oracles.append(o); truth.append(fib)
+    done = 0
+    while done + step <= nf - 1:
+        ctx.process(step)
+        for s, orc in enumerate(oracles):
+            o = orc.process(step)
+            assert o["rc"] == step
+            assert np.array_equal(ctx.sync(s), o["sync"]), f"{names[s]}: sync records"
+            assert np.array_equal(ctx.fic_soft(s), o["fic_soft"]) and np.array_equal(ctx.msc_soft(s), o["msc_soft"]), f"{names[s]}: soft bits"
+            gf, gok = ctx.fib(s)
+            assert np.array_equal(gf, o["fib"]) and np.array_equal(gok, o["fib_ok"])
+            assert gok.all() and np.array_equal(gf, truth[s][done:done + step]), f"{names[s]}: FIBs in frames {done}.."
+            gm, gv = ctx.msc(s)
+            assert np.array_equal(gv, o["msc_valid"]) and np.array_equal(gm[gv == 1], o["msc"][o["msc_valid"] == 1])
+            st, so = ctx.state(s), orc.state()
+            assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"], st["slope"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"], so["slope"])
+        done += step
