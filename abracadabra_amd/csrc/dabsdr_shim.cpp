@@ -149,7 +149,9 @@ int get_component_item(dabsdrHandle_t h, uint8_t idx, dabsdrServiceCompListItem_
     std::memset(out, 0, sizeof *out);
     out->SCIdS = static_cast<uint8_t>(c.scids);
     out->SubChAddr = -1;
-    out->ps = c.primary ? 1 : 0;
+    // P/S bit of FIG 0/2 as the reference reports it: masked, not shifted (the reference's library
+    // returned ps = 2 for a primary component; the host only tests non-zero, radiocontrol.cpp:1522-1523)
+    out->ps = c.primary ? 2 : 0;
     out->CAflag = c.ca;
     out->TMId = static_cast<uint8_t>(c.tmid);
     out->numUserApps = static_cast<uint8_t>(c.apps.size());
@@ -908,6 +910,61 @@ DABSDR_API int dabsdr_amd_fig_dump(const uint8_t *fibs, int n_fibs, char *out, i
     }
     std::snprintf(line, sizeof line, "reconfiguration pending=%d next=%d applied=%d\n", db.change_pending ? 1 : 0, db.next ? 1 : 0, db.reconfigured ? 1 : 0);
     s += line;
+    if (static_cast<int>(s.size()) + 1 > cap) return -1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return static_cast<int>(s.size());
+}
+
+// test hook (CPU only): parse FIBs, then answer GetEnsemble / GetServiceList / GetServiceComponents exactly as the
+// worker does and print the notification structs the host would receive (tests/test_reference_observed.py)
+namespace {
+void struct_dump_cb(dabsdrNotificationCBData_t *d, void *ctx)
+{
+    auto *hs = static_cast<std::pair<dabsdr_s *, std::string *> *>(ctx);
+    std::string &s = *hs->second;
+    char line[256];
+    if (d->nid == DABSDR_NID_ENSEMBLE_INFO) {
+        const auto *e = static_cast<const dabsdrNtfEnsemble_t *>(d->pData);
+        std::snprintf(line, sizeof line, "ENSEMBLE status=%d ueid=0x%08X LTO=%d intTable=%d label='%.16s' charField=0x%04X\n", d->status, e->ueid, e->LTO,
+                      e->intTable, e->label.str, e->label.charField);
+        s += line;
+    } else if (d->nid == DABSDR_NID_SERVICE_LIST) {
+        const auto *l = static_cast<const dabsdrNtfServiceList_t *>(d->pData);
+        std::snprintf(line, sizeof line, "SERVICE_LIST n=%d\n", l->numServices);
+        s += line;
+        for (int i = 0; i < l->numServices; ++i) {
+            dabsdrServiceListItem_t it;
+            l->getServiceListItem(hs->first, static_cast<uint8_t>(i), &it);
+            std::snprintf(line, sizeof line, "  SId=0x%04X label='%.16s' pty=%d/%d CAId=%d\n", it.sid, it.label.str, it.pty.s, it.pty.d, it.CAId);
+            s += line;
+        }
+    } else if (d->nid == DABSDR_NID_SERVICE_COMPONENT_LIST) {
+        const auto *l = static_cast<const dabsdrNtfServiceComponentList_t *>(d->pData);
+        std::snprintf(line, sizeof line, "SC_LIST SId=0x%04X n=%d\n", l->SId, l->numServiceComponents);
+        s += line;
+        for (int i = 0; i < l->numServiceComponents; ++i) {
+            dabsdrServiceCompListItem_t it;
+            l->getServiceComponentListItem(hs->first, static_cast<uint8_t>(i), &it);
+            std::snprintf(line, sizeof line, "  SCIdS=%d SubChId=%d addr=%d size=%d prot=%d ps=%d TMId=%d ASCTy=%d bitrate=%d\n", it.SCIdS, it.SubChId,
+                          it.SubChAddr, it.SubChSize, it.protectionLevel, it.ps, it.TMId, it.streamAudio.ASCTy, it.streamAudio.bitRate);
+            s += line;
+        }
+    }
+}
+}  // namespace
+
+DABSDR_API int dabsdr_amd_struct_dump(const uint8_t *fibs, int n_fibs, char *out, int cap)
+{
+    dabsdr_s h;
+    std::string s;
+    std::pair<dabsdr_s *, std::string *> ctx(&h, &s);
+    h.ntf_cb = struct_dump_cb; h.ntf_ctx = &ctx;
+    for (int i = 0; i < n_fibs; ++i) h.db.parse_fib(fibs + 32 * i);
+    handle_request(&h, {Req::GetEnsemble, 0, 0, 0});
+    handle_request(&h, {Req::GetServiceList, 0, 0, 0});
+    std::vector<uint32_t> sids;
+    for (const auto &kv : h.db.services) sids.push_back(kv.second.sid);
+    for (uint32_t sid : sids) handle_request(&h, {Req::GetServiceComponents, sid, 0, 0});
     if (static_cast<int>(s.size()) + 1 > cap) return -1;
     std::memcpy(out, s.c_str(), s.size() + 1);
     return static_cast<int>(s.size());

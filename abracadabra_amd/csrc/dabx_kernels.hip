@@ -286,10 +286,13 @@ __global__ __launch_bounds__(256) void k_null_search(DevCtx C)
     for (int d = 128; d > 0; d >>= 1) { if (t < d) redv[t] += redv[t + d]; __syncthreads(); }
     tot = redv[0];
     if (t == 0) {
-        if (!(best * 4 * NS_BLOCKS < tot * NS_WIN)) { st.acq_fail = 1; return; }
+        // quietest window at least 2.5 dB below the average window; the null ends where two consecutive blocks rise
+        // above the midpoint between the null's level and the average block energy
+        if (!(best * 16 * NS_BLOCKS < tot * NS_WIN * 9)) { st.acq_fail = 1; return; }
+        const uint64_t mid = best * NS_BLOCKS + tot * NS_WIN;
         int edge = bb + NS_WIN;
         for (int b = bb; b + 1 < NS_BLOCKS + NS_WIN; ++b)
-            if (E[b] * 2 * NS_BLOCKS > tot && E[b + 1] * 2 * NS_BLOCKS > tot) { edge = b; break; }
+            if (E[b] * 2 * NS_WIN * NS_BLOCKS > mid && E[b + 1] * 2 * NS_WIN * NS_BLOCKS > mid) { edge = b; break; }
         st.pos = st.pos + 64 * (int64_t)edge - TNULL;
         st.cif = 0;
         st.acq_fail = 0;

@@ -334,13 +334,15 @@ static int null_search(const orx_t *s, int64_t from, int64_t *null_start)
         for (int j = 0; j < NS_WIN; j++) m += E[b + j];
         if (m < best) { best = m; bb = b; }
     }
-    /* the quietest window must be at least 6 dB below the average window */
-    if (!(best * 4 * NS_BLOCKS < tot * NS_WIN)) { *null_start = from; return 0; }
-    /* the null ends where two consecutive blocks rise above half the average
-     * block energy; the frame starts one null length before that edge */
+    /* the quietest window must be at least 2.5 dB (a factor 9/16) below the average window: a null symbol still
+     * shows at 0 dB SNR (-3 dB), the minimum of 3072 windows of pure noise stays within 0.3 dB of the average */
+    if (!(best * 16 * NS_BLOCKS < tot * NS_WIN * 9)) { *null_start = from; return 0; }
+    /* the null ends where two consecutive blocks rise above the midpoint between the null's level and the
+     * average block energy; the frame starts one null length before that edge */
+    const uint64_t mid = best * NS_BLOCKS + tot * NS_WIN;         /* x 2 NS_WIN NS_BLOCKS */
     int edge = bb + NS_WIN;
     for (int b = bb; b + 1 < NS_BLOCKS + NS_WIN; b++)
-        if (E[b] * 2 * NS_BLOCKS > tot && E[b + 1] * 2 * NS_BLOCKS > tot) { edge = b; break; }
+        if (E[b] * 2 * NS_WIN * NS_BLOCKS > mid && E[b + 1] * 2 * NS_WIN * NS_BLOCKS > mid) { edge = b; break; }
     *null_start = from + 64 * (int64_t)edge - DAB_TNULL;
     return 1;
 }

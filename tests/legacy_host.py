@@ -1,0 +1,115 @@
+"""A minimal host for the reference's 24-function dabsdr API (test helper): what src/radiocontrol.cpp does with
+the library — init, register callbacks, dabsdr(), requests, notifications — over a raw-file style input."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+
+import abracadabra_amd as aa
+from test_gpu_legacy_api import NID, CompItem, CompList, Ensemble, Ntf, Periodic, ServiceItem, ServiceList
+
+TF = 196608
+
+
+class LegacyHost:
+    def __init__(self, samples_f32, gate_at=None):
+        """samples_f32: interleaved I,Q floats the input callback hands out (zeros after the end, like a flushed FIFO).
+        gate_at: sample count (complex) after which the input blocks until open_gate() (the library is un-paced)."""
+        self.L = aa.load_library()
+        self.samples = np.ascontiguousarray(samples_f32, dtype=np.float32)
+        self.pos = 0
+        self.gate_at = gate_at
+        self.gate = threading.Event()
+        self.events, self.lock = [], threading.Lock()
+        self.handle = C.c_void_p()
+        L = self.L
+
+        @C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint16)
+        def get_samples(buf, n):
+            if self.gate_at is not None and self.pos >= 2 * self.gate_at and not self.gate.is_set():
+                self.gate.wait(0.05)
+            out = np.ctypeslib.as_array(buf, shape=(2 * n,))
+            take = self.samples[self.pos:self.pos + 2 * n]
+            out[:len(take)] = take
+            out[len(take):] = 0.0
+            self.pos += 2 * n
+
+        @C.CFUNCTYPE(None, C.POINTER(Ntf), C.c_void_p)
+        def on_ntf(p, ctx):
+            n = p.contents
+            rec = dict(nid=n.nid, status=n.status, len=n.len, at=self.pos // 2)
+            if n.nid == NID["TUNE"]:
+                rec["freq"] = C.cast(n.pData, C.POINTER(C.c_uint32)).contents.value
+            elif n.nid == NID["RESET"]:
+                rec["flag"] = C.cast(n.pData, C.POINTER(C.c_int)).contents.value
+            elif n.nid == NID["SYNC_STATUS"]:
+                rec["level"] = C.cast(n.pData, C.POINTER(C.c_int)).contents.value
+                rec["snr10"] = C.cast(n.pData + 4, C.POINTER(C.c_int16)).contents.value
+            elif n.nid == NID["ENSEMBLE_INFO"]:
+                e = C.cast(n.pData, C.POINTER(Ensemble)).contents
+                rec.update(ueid=e.ueid, lto=e.LTO, label=e.label.str.decode(), charField=e.label.charField, freq=e.frequency)
+            elif n.nid == NID["PERIODIC"] and n.pData:
+                pr = C.cast(n.pData, C.POINTER(Periodic)).contents
+                rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel, snr10=pr.snr10)
+            elif n.nid == NID["SERVICE_LIST"]:
+                sl = C.cast(n.pData, C.POINTER(ServiceList)).contents
+                items = []
+                for i in range(sl.numServices):
+                    it = ServiceItem()
+                    sl.getItem(self.handle, i, C.byref(it))
+                    items.append(dict(sid=it.sid, label=it.label.str.decode(), pty=(it.pty_s, it.pty_d)))
+                rec["services"] = items
+            elif n.nid == NID["SERVICE_COMPONENT_LIST"]:
+                cl = C.cast(n.pData, C.POINTER(CompList)).contents
+                comps = []
+                for i in range(cl.numServiceComponents):
+                    it = CompItem()
+                    cl.getItem(self.handle, i, C.byref(it))
+                    comps.append(dict(scids=it.SCIdS, subch=it.SubChId, addr=it.SubChAddr, size=it.SubChSize, prot=it.protectionLevel, ps=it.ps,
+                                      tmid=it.TMId, ascty=it.u.streamAudio.ASCTy, kbps=it.u.streamAudio.bitRate))
+                rec.update(sid=cl.SId, comps=comps)
+            with self.lock:
+                self.events.append(rec)
+
+        self._keep = (get_samples, on_ntf)
+        L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
+        assert L.dabsdrInit(C.byref(self.handle)) == 0
+        for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+            getattr(L, name)(self.handle, C.cast(get_samples, C.c_void_p))
+        L.dabsdrRegisterNotificationCb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabsdrRegisterNotificationCb(self.handle, C.cast(on_ntf, C.c_void_p), None)
+        for name in ("dabsdr", "dabsdrRequest_GetEnsemble", "dabsdrRequest_GetServiceList", "dabsdrRequest_Exit"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.dabsdrRequest_Tune.argtypes = [C.c_void_p, C.c_uint32]
+        L.dabsdrRequest_SetPeriodicNotify.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32]
+        L.dabsdrRequest_GetServiceComponents.argtypes = [C.c_void_p, C.c_uint32]
+        L.dabsdrRequest_ServiceSelection.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8, C.c_int]
+        L.dabsdr(self.handle)
+
+    def tune(self, khz=225648, periodic=0):
+        self.L.dabsdrRequest_SetPeriodicNotify(self.handle, 1, periodic)
+        self.L.dabsdrRequest_Tune(self.handle, khz)
+
+    def open_gate(self):
+        self.gate.set()
+
+    def wait_for(self, pred, timeout=60.0):
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            with self.lock:
+                hit = [e for e in self.events if pred(e)]
+            if hit:
+                return hit
+            time.sleep(0.02)
+        with self.lock:
+            raise AssertionError(f"timeout; last events: {self.events[-10:]}")
+
+    def close(self):
+        if self.handle:
+            self.L.dabsdrRequest_Exit(self.handle)
+            self.L.dabsdrDeinit.argtypes = [C.POINTER(C.c_void_p)]
+            self.L.dabsdrDeinit(C.byref(self.handle))
+            assert not self.handle.value
+            self.handle = None

@@ -226,7 +226,7 @@ def test_tune_lock_ensemble_and_service_list():
     L.dabsdrRequest_GetAnnouncementSupport.argtypes = [C.c_void_p, C.c_uint32]
     L.dabsdrRequest_GetServiceComponents(handle, 0x1A01)
     cl = wait_for(lambda e: e["nid"] == NID["SERVICE_COMPONENT_LIST"] and e.get("sid") == 0x1A01)[-1]
-    assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, lang=9, napps=1, tmid=0, ascty=63, kbps=64, ps=1)]
+    assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, lang=9, napps=1, tmid=0, ascty=63, kbps=64, ps=2)]
     L.dabsdrRequest_GetUserAppList(handle, 0x1A01, 0)
     ul = wait_for(lambda e: e["nid"] == NID["USER_APP_LIST"] and e.get("sid") == 0x1A01)[-1]
     assert ul["scids"] == 0 and ul["apps"] == [(2, bytes([0x0C, 0x3C]))]                # MOT slide show over X-PAD application type 12

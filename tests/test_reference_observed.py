@@ -1,0 +1,147 @@
+"""What the reference's closed library was OBSERVED to do (the survey session drove
+libdabsdr.so through its public API and recorded the results), encoded as tests.  These are the only
+reference-derived facts available for this path; they narrow the parity gap without closing it (parity stays
+"unpinned" by rule: the binary is not run here, the numbers below are quoted from the survey).
+
+  A.6  FIC sensitivity: FIB error rate 0.205 / 0.022 / 0.002 / 0 at 2 / 3 / 4 / >= 5 dB (AWGN, SNR over the sampled
+       bandwidth, u8 input), lock achieved in all cases
+  A.3/A.4/B  FIG byte strings -> ueid = 0x00E2xxxx, LTO = 2, prot = 8 (EEP 3-A), pty = 255/255, ps = 2, ASCTy 63, 64 kbit/s
+  A.3  SYNC level 3 after ~2 frames;  A.5  freqOffset = +2299.9 / -740.1 for +2300 / -740 Hz; input x256 and x0.01: identical decode
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import abracadabra_amd as aa
+from oracle import binding as ob
+from test_fig_extra import fib, fig0
+
+REF_FER = {2: 0.205, 3: 0.022, 4: 0.002, 5: 0.0}
+
+
+def ref_fer(snr):
+    """the reference's curve between its measured points (log-linear; 1e-4 stands for "0 of 1440" at >= 5 dB)"""
+    pts = {2: 0.205, 3: 0.022, 4: 0.002, 5: 1e-4}
+    lo = min(max(int(math.floor(snr)), 2), 4)
+    a, b = math.log(pts[lo]), math.log(pts[lo + 1])
+    return math.exp(a + (b - a) * (snr - lo))
+
+
+def fer_band(snr):
+    """acceptable FIB error rates at `snr`: what the reference shows 0.5 dB either side, plus the counting noise of 1440 FIBs"""
+    lo, hi = ref_fer(snr + 0.5), ref_fer(snr - 0.5)
+    n = 1440
+    return max(0.0, lo - 3 * math.sqrt(lo / n) - 1.5 / n), hi + 3 * math.sqrt(hi / n) + 1.5 / n
+
+
+def fic_signal(snr, seed):
+    return ob.tx_generate(seed=seed, n_frames=124, subch=[], delay=3000, snr_db=float(snr))
+
+
+def oracle_fer(snr, seed=1):
+    iq, fib_tx, _ = fic_signal(snr, seed)
+    o = ob.Stream(subch=[], ring_len=126 * ob.TF)
+    o.push(iq)
+    bad = tot = 0
+    for _ in range(30):
+        r = o.process(4, want_soft=False)
+        assert r["rc"] == 4, "the reference locked at every SNR of the sweep"
+        tot += r["fib_ok"].size
+        bad += int((r["fib_ok"] == 0).sum())
+    return bad / tot, o.state()["locked"]
+
+
+@pytest.mark.parametrize("snr", [2, 3, 4, 5])
+def test_fic_sensitivity_matches_the_reference_curve(snr):
+    fer, locked = oracle_fer(snr)
+    lo, hi = fer_band(snr)
+    assert locked == 1
+    assert lo <= fer <= hi, f"FIB error rate {fer:.4f} at {snr} dB; the reference showed {REF_FER[snr]} (band {lo:.4f}..{hi:.4f})"
+
+
+def _struct_dump(fibs):
+    L = aa.load_library()
+    L.dabsdr_amd_struct_dump.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(16384)
+    flat = np.frombuffer(b"".join(fibs), dtype=np.uint8).copy()
+    assert L.dabsdr_amd_struct_dump(flat.ctypes.data, len(fibs), buf, 16384) > 0
+    return buf.value.decode()
+
+
+def test_appendix_b_fig_bytes_give_the_structs_the_reference_reported():
+    """the exact FIG byte strings of SURVEY.md Appendix B, the exact struct fields of Appendix A items 3 and 4"""
+    eid, sid = 0x1234, 0x1AB1
+    fig00 = bytes([0x05, 0x00, eid >> 8, eid & 0xFF, 0x00, 0x07])
+    fig09 = bytes([0x04, 0x09, 0x02, 0xE2, 0x00])                         # LTO +1 h (2 half hours), ECC 0xE2
+    fig01 = bytes([0x05, 0x01, 0x00, 0x00, 0x80 | (0 << 4) | (2 << 2) | 0, 48])      # SubCh 0, start 0, long form, EEP-A, level 3-A, 48 CU
+    fig02 = bytes([0x06, 0x02, sid >> 8, sid & 0xFF, 0x01, 0x3F, 0x02])   # one component: TMId 0, ASCTy 63, SubCh 0, primary
+    fig10 = bytes([0x35, 0x00, eid >> 8, eid & 0xFF]) + b"MI355X PROBE ENS" + bytes([0xFF, 0x00])
+    fig11 = bytes([0x35, 0x01, sid >> 8, sid & 0xFF]) + b"PROBE SERVICE 01" + bytes([0xFF, 0x00])
+    text = _struct_dump([fib(fig00, fig01, fig02, fig09), fib(fig10), fib(fig11)])
+    assert "ENSEMBLE status=0 ueid=0x00E21234 LTO=2 intTable=0 label='MI355X PROBE ENS' charField=0xFF00" in text
+    assert "SERVICE_LIST n=1" in text and "SId=0x1AB1 label='PROBE SERVICE 01' pty=255/255" in text
+    assert "SCIdS=0 SubChId=0 addr=0 size=48 prot=8 ps=2 TMId=0 ASCTy=63 bitrate=64" in text
+
+
+def test_unknown_fields_are_reported_as_the_host_expects():
+    """radiocontrol.cpp:1396 accepts an ensemble only with ECC != 0 and a label; :1492-1498 rejects components whose
+    sub-channel is not known yet (SubChAddr < 0)"""
+    sid = 0x1AB1
+    text = _struct_dump([fib(bytes([0x05, 0x00, 0x12, 0x34, 0x00, 0x01]), bytes([0x06, 0x02, sid >> 8, sid & 0xFF, 0x01, 0x3F, 0x02]))])
+    assert "ueid=0x00001234" in text and "label=''" in text            # no FIG 0/9 yet: ECC 0, no label
+    assert "addr=-1" in text                                           # FIG 0/1 not seen yet
+
+
+# ------------------------------------------------------------------------------------------ GPU: the same through the legacy ABI
+@pytest.mark.gpu
+@pytest.mark.parametrize("snr", [2, 3, 4, 5])
+def test_gpu_fic_sensitivity(gpu_ctx_factory, snr):
+    """the GPU chain shows the reference's FIC sensitivity and, FIB by FIB, the oracle's results"""
+    iq, fib_tx, _ = fic_signal(snr, 1)
+    ctx = gpu_ctx_factory(n_streams=1, fmt=0, ring_frames=126, max_frames=4)
+    ctx.push(0, iq)
+    o = ob.Stream(subch=[], ring_len=126 * ob.TF)
+    o.push(iq)
+    bad = tot = 0
+    for _ in range(30):
+        ctx.process(4)
+        r = o.process(4, want_soft=False)
+        gf, gok = ctx.fib(0)
+        assert np.array_equal(gok, r["fib_ok"]) and np.array_equal(gf, r["fib"]) and np.array_equal(ctx.sync(0), r["sync"])
+        tot += gok.size
+        bad += int((gok == 0).sum())
+    lo, hi = fer_band(snr)
+    assert ctx.state(0)["locked"] == 1 and lo <= bad / tot <= hi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfo,scale", [(2300.0, 1.0), (-740.0, 1.0), (2300.0, 256.0), (-740.0, 0.01)])
+def test_gpu_lock_time_frequency_offset_and_input_scale(cfo, scale):
+    """through the float input callback: SYNC level 3 within ~2 frames of input, freqOffset = the applied shift with its
+    sign, and the same ensemble / services whatever the amplitude of the samples (x256, x0.01)"""
+    from legacy_host import NID, LegacyHost
+    sub = [[0, 0, 3, 64]]
+    iq, fib_tx, _ = ob.tx_generate(seed=91, eid=0x1234, n_frames=14, subch=sub, delay=2000, snr_db=30.0, cfo_hz=cfo)
+    host = LegacyHost((iq.astype(np.float32) - 128.0) * np.float32(scale))
+    try:
+        host.tune(periodic=0)
+        sync = host.wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)[0]
+        # the reference reported level 3 at sample ~395 868 = 2.01 frames; this library pulls whole frames: allow 3.2
+        assert sync["at"] <= 3.2 * 196608 + 2000, f"FIC sync only after {sync['at'] / 196608:.2f} frames of input"
+        per = host.wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e.get("level") == 3 and e["at"] > 6 * 196608)[-1]
+        assert per["fib_err"] == 0
+        assert abs(per["foff"] / 10.0 - cfo) < 1.0, f"freqOffset {per['foff'] / 10.0} Hz for a shift of {cfo} Hz"       # reference: 2299.9 / -740.1
+        assert 250 <= per["snr10"] <= 320                                    # reference: 28.5 dB reported for 30 dB in
+        host.L.dabsdrRequest_GetEnsemble(host.handle)
+        ens = host.wait_for(lambda e: e["nid"] == NID["ENSEMBLE_INFO"] and e["status"] == 0)[-1]
+        assert ens["ueid"] == 0x00E21234 and ens["lto"] == 2
+        host.L.dabsdrRequest_GetServiceList(host.handle)
+        sl = host.wait_for(lambda e: e["nid"] == NID["SERVICE_LIST"] and e["services"])[-1]
+        assert [s["sid"] for s in sl["services"]] == [0x1A01] and sl["services"][0]["pty"] == (255, 255)
+        host.L.dabsdrRequest_GetServiceComponents(host.handle, 0x1A01)
+        cl = host.wait_for(lambda e: e["nid"] == NID["SERVICE_COMPONENT_LIST"] and e.get("sid") == 0x1A01)[-1]
+        assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, prot=8, ps=2, tmid=0, ascty=63, kbps=64)]
+    finally:
+        host.close()
