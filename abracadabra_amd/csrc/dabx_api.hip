@@ -5,6 +5,7 @@
 // src/input/inputdevice.cpp:30-131) and the launch sequence of one decode step.
 #include "dabx_kernels.hip"
 #include "dabx_superframe.hip"
+#include "dabx_resample.hip"
 #include "dabx_spec.hpp"
 #include "rawfile.hpp"
 #include "../../include/dabx.h"
@@ -49,6 +50,7 @@ struct StreamHost {
     std::vector<dabx::Profile> prof;
     int msc_bytes = 0;
     uint64_t dabplus = 0;                   // bit k: sub-channel k carries DAB+ audio (dabx_set_dabplus)
+    float rs_mu = 0.0f;                     // Farrow resampler: fractional interval after the last input sample
 };
 
 }  // namespace
@@ -98,6 +100,10 @@ struct dabx_ctx {
     hipEvent_t copy_done = nullptr;
     bool copies_queued = false;
     size_t scratch_words = 0;
+    // sample-rate conversion in front of the ring (dabx_resample.hip)
+    rs::State *d_rs_state = nullptr;        // [S], zeroed
+    uint8_t *d_rs_in = nullptr; float *d_rs_mu = nullptr; int32_t *d_rs_seg = nullptr; float2 *d_rs_A = nullptr, *d_rs_x = nullptr;
+    size_t rs_in_cap = 0, rs_mu_cap = 0, rs_seg_cap = 0, rs_A_cap = 0;
     std::mutex mu;
 
     DevCtx dev() const
@@ -265,6 +271,20 @@ bool valid_stream(const dabx_ctx *c, int s) { return c && s >= 0 && s < c->cfg.n
 
 }  // namespace
 
+namespace {
+template <class T>
+int grow(T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return DABX_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t n = need + need / 2 + 1024;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+    cap = n;
+    return DABX_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char *dabx_strerror(int code)
@@ -343,7 +363,7 @@ void dabx_destroy(dabx_ctx *c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
                     c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
-                    c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic};
+                    c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic, c->d_rs_state, c->d_rs_in, c->d_rs_mu, c->d_rs_seg, c->d_rs_A, c->d_rs_x};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -442,6 +462,104 @@ int dabx_push_all(dabx_ctx *c, const void *src, size_t stride, int64_t n, int ki
     for (int s = 0; s < S; ++s) {
         const int rc = dabx_push(c, s, static_cast<const uint8_t *>(src) + s * stride, n, kind);
         if (rc) return rc;
+    }
+    return DABX_OK;
+}
+
+int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain)
+{
+    if (!valid_stream(c, s) || n < 0 || (n && !src) || (src_fmt != DABX_FMT_S16 && src_fmt != DABX_FMT_F32) || !(in_rate_hz >= 2048000.0) ||
+        in_rate_hz > 32768000.0 || n > (1 << 28) || c->cfg.fmt != DABX_FMT_S16)
+        return DABX_E_ARG;
+    const bool ds2 = in_rate_hz == 4096000.0, copy = in_rate_hz == 2048000.0;
+    if (ds2 && (n & 1)) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    auto &sh = c->streams[s];
+    const int64_t len = c->cfg.ring_samples;
+    const size_t bpc = src_fmt == DABX_FMT_S16 ? 4 : 8;                  // bytes per complex input sample
+    hipStream_t q = c->stream;
+    if (!c->d_rs_state) {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_rs_state), c->cfg.n_streams * sizeof(rs::State)));
+        HIPCHK(hipMemset(c->d_rs_state, 0, c->cfg.n_streams * sizeof(rs::State)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_rs_x), rs::FW_M * sizeof(float2)));
+    }
+    if (n == 0) return 0;
+    int rc;
+    if ((rc = grow(c->d_rs_in, c->rs_in_cap, static_cast<size_t>(n) * bpc))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_rs_in, src, static_cast<size_t>(n) * bpc, hipMemcpyHostToDevice, q));
+    rs::State *st = c->d_rs_state + s;
+    short2 *ring = reinterpret_cast<short2 *>(c->d_ring + static_cast<size_t>(s) * len * c->bps);
+    int64_t n_out = 0;
+    // the reference picks the converter by rate (inputdevicesrc.cpp:33-47)
+    if (copy || ds2) {
+        n_out = copy ? n : n / 2;
+        if (sh.wr + n_out - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
+        const unsigned blocks = static_cast<unsigned>((n_out + 255) / 256);
+        if (copy) {
+            if (src_fmt == DABX_FMT_S16) hipLaunchKernelGGL(rs::k_resample_copy<1>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), ring, len, sh.wr, gain);
+            else hipLaunchKernelGGL(rs::k_resample_copy<2>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), ring, len, sh.wr, gain);
+        } else if (src_fmt == DABX_FMT_S16) {
+            hipLaunchKernelGGL(rs::k_resample_ds2<1>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), st, ring, len, sh.wr, gain);
+            hipLaunchKernelGGL(rs::k_ds2_tail<1>, dim3(1), dim3(64), 0, q, c->d_rs_in, n, st);
+        } else {
+            hipLaunchKernelGGL(rs::k_resample_ds2<2>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), st, ring, len, sh.wr, gain);
+            hipLaunchKernelGGL(rs::k_ds2_tail<2>, dim3(1), dim3(64), 0, q, c->d_rs_in, n, st);
+        }
+    } else {
+        // the schedule of the transposed Farrow structure does not depend on the data: mu <- mu - R, a dump (one output)
+        // whenever it turns negative (inputdevicesrc.cpp:241-245).  The recursion is serial in float, so the host runs
+        // it ahead; the kernels do the arithmetic on the samples.
+        const float R = static_cast<float>(2048e3 / static_cast<double>(static_cast<float>(in_rate_hz)));
+        std::vector<float> mu(static_cast<size_t>(n));
+        std::vector<int32_t> seg(1, 0);
+        float m = sh.rs_mu;
+        for (int64_t k = 0; k < n; ++k) {
+            m = m - R;
+            if (m < 0) { m = m + 1.0f; seg.push_back(static_cast<int32_t>(k)); }
+            mu[static_cast<size_t>(k)] = m;
+        }
+        const int n_done = static_cast<int>(seg.size()) - 1;
+        n_out = n_done;
+        if (sh.wr + n_out - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
+        if ((rc = grow(c->d_rs_mu, c->rs_mu_cap, mu.size())) || (rc = grow(c->d_rs_seg, c->rs_seg_cap, seg.size())) ||
+            (rc = grow(c->d_rs_A, c->rs_A_cap, static_cast<size_t>(n_done + 1) * rs::FW_N)))
+            return rc;
+        HIPCHK(hipMemcpyAsync(c->d_rs_mu, mu.data(), mu.size() * sizeof(float), hipMemcpyHostToDevice, q));
+        HIPCHK(hipMemcpyAsync(c->d_rs_seg, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, q));
+        const unsigned blocks = static_cast<unsigned>((n_done + 255) / 256);
+        if (src_fmt == DABX_FMT_S16) {
+            if (n_done) hipLaunchKernelGGL(rs::k_farrow_segments<1>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, st, c->d_rs_A);
+            hipLaunchKernelGGL(rs::k_farrow_open<1>, dim3(1), dim3(64), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, n, st, c->d_rs_x);
+        } else {
+            if (n_done) hipLaunchKernelGGL(rs::k_farrow_segments<2>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, st, c->d_rs_A);
+            hipLaunchKernelGGL(rs::k_farrow_open<2>, dim3(1), dim3(64), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, n, st, c->d_rs_x);
+        }
+        if (n_done) hipLaunchKernelGGL(rs::k_farrow_outputs, dim3(blocks), dim3(256), 0, q, c->d_rs_A, n_done, st, ring, len, sh.wr, R, gain);
+        hipLaunchKernelGGL(rs::k_farrow_tail, dim3(1), dim3(64), 0, q, c->d_rs_A, n_done, st, c->d_rs_x);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(q));             // the host vectors go out of scope
+        sh.rs_mu = m;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(q));                 // the caller may reuse its buffer
+    sh.wr += n_out;
+    return n_out;
+}
+
+int dabx_read_ring(dabx_ctx *c, int s, int64_t from, int64_t n, void *dst)
+{
+    if (!valid_stream(c, s) || from < 0 || n < 0 || (n && !dst) || n > c->cfg.ring_samples) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    const int64_t len = c->cfg.ring_samples;
+    const uint8_t *ring = c->d_ring + static_cast<size_t>(s) * len * c->bps;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int64_t done = 0;
+    while (done < n) {
+        const int64_t w = (from + done) % len, chunk = std::min(n - done, len - w);
+        HIPCHK(hipMemcpy(static_cast<uint8_t *>(dst) + done * c->bps, ring + w * c->bps, static_cast<size_t>(chunk) * c->bps, hipMemcpyDeviceToHost));
+        done += chunk;
     }
     return DABX_OK;
 }

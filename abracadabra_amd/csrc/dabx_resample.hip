@@ -1,0 +1,209 @@
+// dabx_resample.hip — sample-rate conversion in front of the ring (gfx950).
+//
+// Replaces the reference's host-side converters that SDR devices run before the dabsdr input FIFO
+// (reference: src/input/inputdevicesrc.h:78-150; selection src/input/inputdevicesrc.cpp:33-47):
+//   k_resample_ds2     4096 kHz -> 2048 kHz, 43-tap half-band FIR          (inputdevicesrc.cpp:109-200)
+//   k_farrow_segments  any rate -> 2048 kHz, transposed Farrow, 6 x 4      (inputdevicesrc.cpp:233-316)
+//   k_farrow_outputs
+// writing s16 IQ straight into the stream's ring.  Same float operations in the same order as the cited lines
+// (one binary32 operation per step, no contraction), so the results equal the CPU checker (oracle/dab_src.c)
+// bit for bit.  The reference's signal-level detector (a serial attack/release recursion used for device gain
+// control) is not part of the decode path and is not computed here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rs {
+
+constexpr int DS2_TAPS = 43, DS2_HIST = DS2_TAPS - 1;
+__constant__ float ds2_coef[12] = {          // inputdevicesrc.h:105-109
+    0.000223158782894952853123604619156594708f,  -0.00070774549637065342286290636764078954f,  0.001735782601167994458266075064045708132f,
+    -0.003619832275410410967614316390950079949f, 0.006788741778432844271862212082169207861f,  -0.01183550169261274320753329902800032869f,
+    0.019680477383812611941182879604639310855f,  -0.032073581325677551212560700832909788005f, 0.053382280107447499517547839786857366562f,
+    -0.099631117404426483563639749263529665768f, 0.316099577146216947909351802081800997257f,  0.5f};
+constexpr int FW_M = 4, FW_N = 6;
+__constant__ float fw_coef[FW_N][FW_M] = {   // inputdevicesrc.h:142-149
+    {0.001667349914006070960362f, 0.032712194697834547085780f, -0.146457831613232558609639f, 0.004040531324696360060411f},
+    {-0.103347648141097675500433f, -0.244367915078825215235980f, 0.233146907266815583970043f, 0.243745693669456003904727f},
+    {0.123959393981824803065983f, 0.873574620095563081356715f, 0.586104518066954516264389f, -0.711183949124104208827646f},
+    {0.873450879200179830519346f, 0.039931348783534291457809f, -1.514110581690161660972649f, 0.711183949124100878158572f},
+    {0.114518381640217964401174f, -0.923204505507555395205088f, 0.952958408884428287421997f, -0.243745693669455892882425f},
+    {-0.104194288733202022889657f, 0.243880907754789599817258f, -0.134525637544989168370435f, -0.004040531324696002707375f},
+};
+
+struct State {                       // per stream, device memory
+    float2 ds2_hist[DS2_HIST];       // the 42 input samples before the next one, oldest first
+    float2 fw_x[FW_M];               // Farrow: integrators of the segment in progress
+    float2 fw_a[FW_N - 1][FW_N];     // Farrow: polynomial outputs A_n of the last five finished segments, oldest first
+};
+
+template <int FMT>                   // 1: s16 pairs, 2: float pairs
+__device__ __forceinline__ float2 in_sample(const void *in, int64_t k)
+{
+    if (FMT == 1) { const short2 v = reinterpret_cast<const short2 *>(in)[k]; return make_float2((float)v.x, (float)v.y); }
+    return reinterpret_cast<const float2 *>(in)[k];
+}
+
+__device__ __forceinline__ short2 to_s16(float2 y, float gain)
+{
+    float a = rintf(y.x * gain), b = rintf(y.y * gain);
+    a = __builtin_amdgcn_fmed3f(a, -32768.0f, 32767.0f); b = __builtin_amdgcn_fmed3f(b, -32768.0f, 32767.0f);
+    return make_short2((short)a, (short)b);
+}
+
+// one output per thread: y[n] = sum_c coef[c] (x[2n-42+2c] + x[2n-2c]) + 0.5 x[2n-21]
+template <int FMT>
+__global__ __launch_bounds__(256) void k_resample_ds2(const void *in, int n_out, const State *st, short2 *ring, int64_t ring_len, int64_t wr,
+                                                      float gain)
+{
+    __shared__ float2 x[2 * 256 + DS2_HIST];
+    const int t = threadIdx.x, n0 = blockIdx.x * 256;
+    for (int k = t; k < 2 * 256 + DS2_HIST; k += 256) {          // x[k] = input sample 2 n0 - 42 + k
+        const int64_t idx = 2 * (int64_t)n0 - DS2_HIST + k;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (idx < 0) v = st->ds2_hist[DS2_HIST + idx];
+        else if (idx < 2 * (int64_t)n_out) v = in_sample<FMT>(in, idx);
+        x[k] = v;
+    }
+    __syncthreads();
+    const int n = n0 + t;
+    if (n >= n_out) return;
+    float accI = 0.0f, accQ = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 11; ++c) {
+        const float2 o = x[2 * t + 2 * c], w = x[2 * t + DS2_HIST - 2 * c];
+        float u = o.x + w.x;
+        u = u * ds2_coef[c];
+        accI = accI + u;
+        u = o.y + w.y;
+        u = u * ds2_coef[c];
+        accQ = accQ + u;
+    }
+    {
+        const float2 m = x[2 * t + 21];
+        float u = m.x * ds2_coef[11];
+        accI = accI + u;
+        u = m.y * ds2_coef[11];
+        accQ = accQ + u;
+    }
+    int64_t w = wr + n;
+    w = w % ring_len;
+    ring[w] = to_s16(make_float2(accI, accQ), gain);
+}
+
+// after the block: the history for the next call = the last 42 input samples (n_in even, >= 0)
+template <int FMT>
+__global__ void k_ds2_tail(const void *in, int64_t n_in, State *st)
+{
+    const int t = threadIdx.x;
+    if (t >= DS2_HIST) return;
+    const int64_t idx = n_in - DS2_HIST + t;
+    const float2 v = idx >= 0 ? in_sample<FMT>(in, idx) : st->ds2_hist[DS2_HIST + idx];     // idx < 0: the block was shorter than the history
+    __syncthreads();
+    st->ds2_hist[t] = v;
+}
+
+// pass-through (2048 kHz in): float or s16 -> the ring's s16
+template <int FMT>
+__global__ __launch_bounds__(256) void k_resample_copy(const void *in, int n, short2 *ring, int64_t ring_len, int64_t wr, float gain)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    ring[(wr + k) % ring_len] = to_s16(in_sample<FMT>(in, k), gain);
+}
+
+// Transposed Farrow, pass 1: one thread per segment (the input samples integrated between two dumps).
+//   seg[j] .. seg[j+1]-1: the segment's input samples; mu[k]: the fractional interval sample k is integrated with —
+//   the data-independent schedule the host runs ahead (the reference's mu recursion is serial in float).
+// Segment 0 continues the integrators carried over from the previous call.  A[j][n] = sum_m x[m] coef[n][m].
+template <int FMT>
+__global__ __launch_bounds__(256) void k_farrow_segments(const void *in, const int32_t *seg, const float *mu, int n_seg, const State *st,
+                                                         float2 *A /*[n_seg][6]*/)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_seg) return;
+    float2 x[FW_M];
+#pragma unroll
+    for (int m = 0; m < FW_M; ++m) x[m] = j == 0 ? st->fw_x[m] : make_float2(0.0f, 0.0f);
+    for (int k = seg[j]; k < seg[j + 1]; ++k) {
+        float2 v = in_sample<FMT>(in, k);
+        const float u = mu[k];
+        x[0].x = x[0].x + v.x; x[0].y = x[0].y + v.y;
+#pragma unroll
+        for (int m = 1; m < FW_M; ++m) {
+            v.x = v.x * u; v.y = v.y * u;
+            x[m].x = x[m].x + v.x; x[m].y = x[m].y + v.y;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < FW_N; ++n) {
+        float aI = 0.0f, aQ = 0.0f;
+#pragma unroll
+        for (int m = 0; m < FW_M; ++m) {
+            float p = x[m].x * fw_coef[n][m];
+            aI = aI + p;
+            p = x[m].y * fw_coef[n][m];
+            aQ = aQ + p;
+        }
+        A[(size_t)j * FW_N + n] = make_float2(aI, aQ);
+    }
+}
+
+// pass 2: output j (dumped when segment j closes) = R (((((A5(j-5) + A4(j-4)) + A3(j-3)) + A2(j-2)) + A1(j-1)) + A0(j)):
+// the order in which the reference's delay line y[] picks the contributions up.  n_done segments are complete (the last
+// segment of a call may still be open).
+__global__ __launch_bounds__(256) void k_farrow_outputs(const float2 *A, int n_done, const State *st, short2 *ring, int64_t ring_len, int64_t wr,
+                                                        float R, float gain)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_done) {
+        float yI = 0.0f, yQ = 0.0f;
+#pragma unroll
+        for (int i = FW_N - 1; i >= 0; --i) {
+            const int s = j - i;                          // segment whose polynomial i lands in this output
+            const float2 a = s >= 0 ? A[(size_t)s * FW_N + i] : st->fw_a[FW_N - 1 + s][i];
+            yI = yI + a.x; yQ = yQ + a.y;
+        }
+        ring[(wr + j) % ring_len] = to_s16(make_float2(R * yI, R * yQ), gain);
+    }
+}
+
+// carry-over for the next call: A of the last five finished segments and the integrators of the open one
+__global__ void k_farrow_tail(const float2 *A, int n_done, State *st, const float2 *x_open)
+{
+    const int t = threadIdx.x;                            // 64 threads
+    float2 v = make_float2(0.0f, 0.0f);
+    const int r = t / FW_N, n = t % FW_N;                 // row r of the new fw_a: segment n_done - 5 + r
+    if (t < (FW_N - 1) * FW_N) {
+        const int s = n_done - (FW_N - 1) + r;
+        v = s >= 0 ? A[(size_t)s * FW_N + n] : st->fw_a[FW_N - 1 + s][n];
+    }
+    float2 xo = make_float2(0.0f, 0.0f);
+    if (t < FW_M) xo = x_open[t];
+    __syncthreads();
+    if (t < (FW_N - 1) * FW_N) st->fw_a[r][n] = v;
+    if (t < FW_M) st->fw_x[t] = xo;
+}
+
+// integrators of the open (last, unfinished) segment of a call, continued from the carried state when it is segment 0
+template <int FMT>
+__global__ void k_farrow_open(const void *in, const int32_t *seg, const float *mu, int j, int64_t n_in, const State *st, float2 *x_open)
+{
+    if (threadIdx.x != 0) return;
+    float2 x[FW_M];
+#pragma unroll
+    for (int m = 0; m < FW_M; ++m) x[m] = j == 0 ? st->fw_x[m] : make_float2(0.0f, 0.0f);
+    for (int64_t k = seg[j]; k < n_in; ++k) {
+        float2 v = in_sample<FMT>(in, k);
+        const float u = mu[k];
+        x[0].x = x[0].x + v.x; x[0].y = x[0].y + v.y;
+#pragma unroll
+        for (int m = 1; m < FW_M; ++m) {
+            v.x = v.x * u; v.y = v.y * u;
+            x[m].x = x[m].x + v.x; x[m].y = x[m].y + v.y;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < FW_M; ++m) x_open[m] = x[m];
+}
+
+}  // namespace rs

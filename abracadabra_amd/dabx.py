@@ -20,6 +20,7 @@ SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("pe
 # every symbol include/dabx.h declares; tests check that the library exports them all
 DABX_SYMBOLS = [
     "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_push_all", "dabx_set_dabplus", "dabx_get_superframes", "dabx_get_superframe_stats", "dabx_alloc_pinned", "dabx_free_pinned", "dabx_ring_ptr",
+    "dabx_push_resampled", "dabx_read_ring",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
     "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum",
@@ -189,6 +190,23 @@ class Context:
     def free_pinned(self, arr):
         self.L.dabx_free_pinned.argtypes = [C.c_void_p]
         self.L.dabx_free_pinned(C.c_void_p(arr.ctypes.data))
+
+    def push_resampled(self, stream, iq, in_rate_hz, gain=1.0):
+        """iq: interleaved I,Q as int16 or float32 at in_rate_hz; returns the number of 2.048 Msps samples appended"""
+        iq = np.ascontiguousarray(iq)
+        fmt = {np.dtype(np.int16): 1, np.dtype(np.float32): 2}[iq.dtype]
+        self.L.dabx_push_resampled.restype = C.c_int64
+        self.L.dabx_push_resampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_float]
+        n = self.L.dabx_push_resampled(self.h, stream, iq.ctypes.data, iq.size // 2, fmt, float(in_rate_hz), float(gain))
+        if n < 0:
+            _chk(int(n))
+        return int(n)
+
+    def read_ring(self, stream, start, n):
+        out = np.zeros(2 * n, dtype=np.int16 if self.fmt else np.uint8)
+        self.L.dabx_read_ring.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+        _chk(self.L.dabx_read_ring(self.h, stream, start, n, out.ctypes.data))
+        return out
 
     def push_device(self, stream, dev_ptr, n_samples):
         _chk(self.L.dabx_push(self.h, stream, C.c_void_p(dev_ptr), n_samples, 1))

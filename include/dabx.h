@@ -118,6 +118,19 @@ DABX_API int dabx_push(dabx_ctx *ctx, int stream, const void *src, int64_t n, in
  * n_streams copies. */
 DABX_API int dabx_push_all(dabx_ctx *ctx, const void *src, size_t src_stride_bytes, int64_t n, int src_kind);
 
+/* Samples at another rate: the converters SDR devices run in front of the reference's FIFO (reference:
+ * src/input/inputdevicesrc.h:78-150, selection src/input/inputdevicesrc.cpp:33-47), on the GPU, writing into the
+ * stream's ring (the context must have been created with DABX_FMT_S16).
+ *   in_rate_hz 2048000: conversion only; 4096000: 43-tap half-band decimator (n even); any other rate: transposed
+ *   Farrow resampler.  src: host memory, n complex samples, interleaved I,Q as int16 (DABX_FMT_S16) or float
+ *   (DABX_FMT_F32); every output sample is multiplied by `gain` and rounded to int16 (1.0 for int16 input; e.g.
+ *   8192 for floats in +-1).  Filter state is kept per stream from call to call.  Returns the number of samples
+ *   appended to the ring, or a negative error code.  The reference's signal-level output is not produced. */
+#define DABX_FMT_F32 2
+DABX_API int64_t dabx_push_resampled(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain);
+/* Test/diagnostic accessor: copies n complex samples starting at absolute sample index `from` out of a stream's ring. */
+DABX_API int dabx_read_ring(dabx_ctx *ctx, int stream, int64_t from, int64_t n, void *dst);
+
 /* Page-locked host buffers for DABX_SRC_PINNED (a file reader fills them directly, as RawFileWorker
  * fills its read buffer: reference src/input/rawfileinput.cpp:640-713). */
 DABX_API void *dabx_alloc_pinned(size_t bytes);

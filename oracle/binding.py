@@ -292,3 +292,46 @@ def rs_decode(cw):
     L.dab_rs_decode_120_110.argtypes = [C.c_void_p]
     r = L.dab_rs_decode_120_110(cw.ctypes.data)
     return r, cw
+
+
+class Resampler:
+    """oracle/dab_src.c: the reference's InputDeviceSRC converters (inputdevicesrc.cpp:33-47 picks by rate)"""
+
+    def __init__(self, in_rate_hz):
+        self.L = lib()
+        self.rate = float(in_rate_hz)
+        self.kind = "copy" if self.rate == 2048e3 else ("ds2" if self.rate == 4096e3 else "farrow")
+        self.L.osrc_sizeof_ds2.restype = self.L.osrc_sizeof_farrow.restype = C.c_int
+        self.state = np.zeros(max(self.L.osrc_sizeof_ds2(), self.L.osrc_sizeof_farrow()) + 16, dtype=np.uint8)
+        self.L.osrc_ds2_reset.argtypes = [C.c_void_p]
+        self.L.osrc_farrow_reset.argtypes = [C.c_void_p, C.c_float]
+        self.L.osrc_ds2_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self.L.osrc_farrow_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.osrc_ds2_level.restype = self.L.osrc_farrow_level.restype = C.c_float
+        self.L.osrc_ds2_level.argtypes = self.L.osrc_farrow_level.argtypes = [C.c_void_p]
+        if self.kind == "ds2":
+            self.L.osrc_ds2_reset(self.state.ctypes.data)
+        elif self.kind == "farrow":
+            self.L.osrc_farrow_reset(self.state.ctypes.data, self.rate)
+
+    def process(self, iq_f32):
+        """iq_f32: interleaved I,Q float32; returns the float32 output samples (interleaved)"""
+        x = np.ascontiguousarray(iq_f32, dtype=np.float32)
+        n = x.size // 2
+        if self.kind == "copy":
+            return x.copy()
+        out = np.zeros(2 * (n + 8), dtype=np.float32)
+        if self.kind == "ds2":
+            m = self.L.osrc_ds2_process(self.state.ctypes.data, x.ctypes.data, n, out.ctypes.data)
+        else:
+            m = self.L.osrc_farrow_process(self.state.ctypes.data, x.ctypes.data, n, out.ctypes.data, None, None)
+        return out[:2 * m].copy()
+
+    def level(self):
+        return float(self.L.osrc_ds2_level(self.state.ctypes.data) if self.kind == "ds2" else self.L.osrc_farrow_level(self.state.ctypes.data))
+
+
+def to_s16(y, gain=1.0):
+    """the ring's sample format: rint(y * gain) clamped to int16 (one float32 multiply, round to nearest even)"""
+    v = np.rint(np.asarray(y, dtype=np.float32) * np.float32(gain))
+    return np.clip(v, -32768, 32767).astype(np.int16)
