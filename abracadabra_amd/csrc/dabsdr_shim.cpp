@@ -18,11 +18,13 @@
 #include <pthread.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -31,13 +33,14 @@
 namespace {
 
 enum class Req { Tune, GetEnsemble, GetServiceList, GetServiceComponents, GetUserAppList, GetAnnouncementSupport,
-                 ServiceSelection, ServiceStop, XPadAppStart, SetPeriodicNotify, SetTII, SignalSpectrum, Exit };
+                 ServiceSelection, ServiceStop, XPadAppStart, SetPeriodicNotify, SetTII, SignalSpectrum, InjectFibs, Exit };
 
 struct Request {
     Req kind;
     uint32_t a = 0;      // frequency / SId
     int32_t b = 0;       // SCIdS / period / enable
     int32_t c = 0;       // decoder id / cfg
+    std::vector<uint8_t> blob;   // InjectFibs (test hook): FIBs of 32 bytes
 };
 
 constexpr int kPullChunk = 16384;        // complex samples per input-callback call (uint16_t length)
@@ -59,6 +62,7 @@ struct Selection {
     std::vector<figdb::UserApp> apps;     // FIG 0/13: maps X-PAD application types to user application types
     pad::Decoder pad;                     // X-PAD -> dynamic label / data groups
     packet::Decoder pkt;                  // packet mode -> data groups
+    std::set<int> xpad_on;                // X-PAD application types the host started (dabsdrRequest_XPadAppStart)
     std::vector<uint8_t> mp2_half;        // first half of a 24 kHz Layer II frame
     uint32_t sf_stats[6] = {0};           // k_superframe totals of this sub-channel
 };
@@ -83,6 +87,11 @@ struct dabsdr_s {
     uint32_t frequency = 0;
     int gain_shift = 0;                  // float -> s16 scaling: x * 2^gain_shift
     bool gain_set = false;
+    std::vector<float> first_frame;      // input held back until one whole frame has been seen (the gain is fixed on it)
+    float frame_peak = 0.0f;             // |sample| peak of the frame in progress (gain hysteresis)
+    int frame_fill = 0;
+    int msc_stride = 0;                  // bytes per CIF of the running selections, as the GPU context has them
+    std::atomic<bool> worker_done{false};
     dabsdrSyncLevel_t sync_level = DABSDR_SYNC_LEVEL_NO_SYNC;
     int period_log2 = -1;                // periodic notification every 2^n frames, <0 = off
     int period_frames = 0;
@@ -217,9 +226,27 @@ bool apply_selections(dabsdr_s *h)
         subs.push_back(h->sel[k]->sub);
         if (!h->sel[k]->packet && h->sel[k]->ascty == 63) dabplus |= 1ull << k;
     }
-    if (dabx_set_subchannels(h->ctx, 0, static_cast<int>(subs.size()), subs.empty() ? nullptr : subs.data()) < 0) return false;
+    const int stride = dabx_set_subchannels(h->ctx, 0, static_cast<int>(subs.size()), subs.empty() ? nullptr : subs.data());
+    if (stride < 0) return false;
+    h->msc_stride = stride;
     if (dabplus && dabx_set_dabplus(h->ctx, 0, dabplus) != DABX_OK) return false;
     return true;                                           // running decoders (and their super frame state on the GPU) carry on
+}
+
+// The same, insisting: a selection the GPU context refuses (a sub-channel a corrupt or hostile FIC describes beyond the
+// 864 CU, an unknown protection profile) is dropped and reported stopped, until the context and h->sel agree again.
+void apply_selections_or_drop(dabsdr_s *h)
+{
+    while (!apply_selections(h)) {
+        if (h->sel.empty() || !h->ctx) { h->msc_stride = 0; return; }
+        // find one selection the context refuses on its own; failing that, give up the newest
+        size_t victim = h->sel.size() - 1;
+        for (size_t k = 0; k < h->sel.size(); ++k)
+            if (dabx_set_subchannels(h->ctx, 0, 1, &h->sel[k]->sub) < 0) { victim = k; break; }
+        dabsdrNtfServiceStop_t stop = {h->sel[victim]->sid, static_cast<uint8_t>(h->sel[victim]->scids), h->sel[victim]->id};
+        h->sel.erase(h->sel.begin() + static_cast<long>(victim));
+        notify(h, DABSDR_NID_SERVICE_STOP, DABSDR_NSTAT_SERVICE_NOT_SUPPORTED, &stop, sizeof stop);
+    }
 }
 
 void wire_callbacks(dabsdr_s *h, Selection *sp)
@@ -230,7 +257,8 @@ void wire_callbacks(dabsdr_s *h, Selection *sp)
         h->dl_cb(&cb, h->dl_ctx);
     };
     sp->pad.on_data_group = [h, sp](int xpad_app, const uint8_t *d, int n) {
-        if (!h->dg_cb) return;
+        // X-PAD applications run only while the host has them started (radiocontrol.cpp:601-618 starts / stops the slide show)
+        if (!h->dg_cb || !sp->xpad_on.count(xpad_app)) return;
         uint16_t type = xpad_app == 12 ? 0x002 : 0;                   // default: MOT slide show; else what FIG 0/13 announces
         for (const auto &a : sp->apps)
             if (!a.data.empty() && (a.data[0] & 0x1F) == xpad_app) type = static_cast<uint16_t>(a.type);
@@ -245,6 +273,8 @@ void wire_callbacks(dabsdr_s *h, Selection *sp)
     };
 }
 
+bool after_fibs(dabsdr_s *h);
+
 void handle_request(dabsdr_s *h, const Request &r)
 {
     switch (r.kind) {
@@ -257,6 +287,8 @@ void handle_request(dabsdr_s *h, const Request &r)
         } else {
             h->frequency = r.a;
             h->gain_set = false;
+            h->first_frame.clear();
+            h->msc_stride = 0;
             // a fresh context state: drop everything buffered so far
             if (h->ctx) {
                 dabx_config_t cfg = {1, DABX_FMT_S16, 8LL * DABX_FRAME_SAMPLES, 1, 0};
@@ -370,17 +402,24 @@ void handle_request(dabsdr_s *h, const Request &r)
                 if (!it->second.long_form) sp->sub = {it->second.start, 2, it->second.uep_index, 0};   // UEP short form
                 if (pk) sp->pkt.address = pk->packet_address;
                 // an audio decoder id holds one component; a data component replaces an earlier selection of itself
-                std::vector<std::unique_ptr<Selection>> keep;
+                std::vector<std::unique_ptr<Selection>> keep, displaced;
                 for (auto &o : h->sel) {
                     const bool same = sp->id == DABSDR_ID_DATA ? (o->id == DABSDR_ID_DATA && o->sid == sp->sid && o->scids == sp->scids) : o->id == sp->id;
-                    if (!same) keep.push_back(std::move(o));
+                    (same ? displaced : keep).push_back(std::move(o));
                 }
                 h->sel = std::move(keep);
                 wire_callbacks(h, sp.get());
-                if (sp->id == DABSDR_ID_AUDIO_PRIMARY) std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
+                const bool primary = sp->id == DABSDR_ID_AUDIO_PRIMARY;
                 h->sel.push_back(std::move(sp));
-                if (apply_selections(h)) st = DABSDR_NSTAT_SUCCESS;
-                else { h->sel.pop_back(); apply_selections(h); st = DABSDR_NSTAT_SERVICE_NOT_SUPPORTED; }
+                if (apply_selections(h)) {
+                    st = DABSDR_NSTAT_SUCCESS;
+                    if (primary) std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
+                } else {                                   // the decoder that was running on this id carries on
+                    h->sel.pop_back();
+                    for (auto &o : displaced) h->sel.push_back(std::move(o));
+                    apply_selections_or_drop(h);
+                    st = DABSDR_NSTAT_SERVICE_NOT_SUPPORTED;
+                }
                 break;
             }
         }
@@ -396,13 +435,20 @@ void handle_request(dabsdr_s *h, const Request &r)
             if (!hit) keep.push_back(std::move(o));
         }
         h->sel = std::move(keep);
-        apply_selections(h);
+        apply_selections_or_drop(h);
         notify(h, DABSDR_NID_SERVICE_STOP, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
         break;
     }
     case Req::XPadAppStart: {
+        // start / stop the delivery of one X-PAD application type (e.g. 12: MOT slide show) of the audio decoder r.c
         dabsdrNtfXpadAppStartStop_t x = {static_cast<uint8_t>(r.a), static_cast<int8_t>(r.b)};
-        notify(h, DABSDR_NID_XPAD_APP_START_STOP, DABSDR_NSTAT_SUCCESS, &x, sizeof x);
+        dabsdrNotificationStatus_t st = DABSDR_NSTAT_SERVICE_NOT_FOUND;
+        for (auto &sp : h->sel)
+            if (sp->id == static_cast<dabsdrDecoderId_t>(r.c) && !sp->packet) {
+                if (r.b) sp->xpad_on.insert(static_cast<int>(r.a)); else sp->xpad_on.erase(static_cast<int>(r.a));
+                st = DABSDR_NSTAT_SUCCESS;
+            }
+        notify(h, DABSDR_NID_XPAD_APP_START_STOP, st, &x, sizeof x);
         break;
     }
     case Req::SetPeriodicNotify:
@@ -419,31 +465,52 @@ void handle_request(dabsdr_s *h, const Request &r)
         h->tii_mode = r.b;
         if (h->ctx) dabx_enable_spectrum(h->ctx, (h->spectrum_on ? 1 : 0) | 2);
         break;
+    case Req::InjectFibs:                                   // test hook: FIBs as if the FIC had delivered them
+        for (size_t o = 0; o + 32 <= r.blob.size(); o += 32) h->db.parse_fib(r.blob.data() + o);
+        after_fibs(h);
+        break;
     case Req::Exit:
         break;
     }
 }
 
-// float IQ from the host -> s16 IQ.  Raw-file input arrives as exact integers
-// (reference: src/input/rawfileinput.cpp:657,692), for which the shift is 0 and
-// the conversion is lossless; other amplitudes get a power-of-two gain.
+// float IQ from the host -> s16 IQ with a power-of-two gain.  Raw-file input arrives as exact integers
+// (reference: src/input/rawfileinput.cpp:657,692): as long as those fit int16 the gain is 1 and the conversion is
+// lossless.  Anything else (SDR floats in +-1, scaled recordings) gets a gain that puts the peak of the FIRST WHOLE
+// FRAME between 2^12 and 2^13 — headroom of 12 dB upwards, 12 bits downwards — and a slow hysteresis afterwards: a
+// frame that peaks above 30000 halves the gain, one that stays below 256 doubles it.  The receiver normalises every
+// OFDM symbol on its own, so a gain step costs at most the symbol it falls into.
+int choose_shift(const float *in, size_t n_values)
+{
+    float mx = 0.0f;
+    bool integral = true;
+    for (size_t i = 0; i < n_values; ++i) {
+        mx = std::fmax(mx, std::fabs(in[i]));
+        integral = integral && in[i] == std::nearbyint(in[i]);
+    }
+    if (!(mx > 0.0f) || !std::isfinite(mx)) return 0;
+    if (integral && mx <= 32767.0f && mx >= 16.0f) return 0;           // integer samples that fit: lossless
+    int sh = 0;
+    while (mx * std::ldexp(1.0f, sh) >= 8192.0f) --sh;
+    while (mx * std::ldexp(1.0f, sh) < 4096.0f && sh < 40) ++sh;
+    return sh;
+}
+
 void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
 {
-    if (!h->gain_set) {
-        float mx = 0.0f;
-        for (int i = 0; i < n_values; ++i) mx = std::fmax(mx, std::fabs(in[i]));
-        int sh = 0;
-        if (mx > 0.0f) {
-            while (mx * std::ldexp(1.0f, sh) > 16384.0f) --sh;
-            while (mx * std::ldexp(1.0f, sh) < 64.0f && sh < 24) ++sh;
-        }
-        h->gain_shift = sh;
-        h->gain_set = mx > 0.0f;
-    }
     const float g = std::ldexp(1.0f, h->gain_shift);
+    float peak = h->frame_peak;
     for (int i = 0; i < n_values; ++i) {
         float v = std::nearbyint(in[i] * g);
+        peak = std::fmax(peak, std::fabs(v));
         out[i] = static_cast<int16_t>(v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v));
+    }
+    h->frame_peak = peak;
+    h->frame_fill += n_values / 2;
+    if (h->frame_fill >= DABX_FRAME_SAMPLES) {                          // once per frame: hysteresis
+        if (peak > 30000.0f) --h->gain_shift;
+        else if (peak < 256.0f && peak > 0.0f && h->gain_shift < 40) ++h->gain_shift;
+        h->frame_fill = 0; h->frame_peak = 0.0f;
     }
 }
 
@@ -463,37 +530,10 @@ void feed_mp2_pad(Selection *sp, const uint8_t *frame, int len)
     else sp->pad.feed_mp2_frame(frame, len);
 }
 
-void after_step(dabsdr_s *h)
+// what the FIG database learnt from the FIBs just parsed: multiplex reconfiguration, another ensemble, changed user
+// applications, programme type, announcement switching.  Returns false when the receiver was reset.
+bool after_fibs(dabsdr_s *h)
 {
-    uint8_t fib[12 * 32], ok[12];
-    dabx_stream_state_t st;
-    dabx_sync_rec_t rec;
-    if (dabx_get_fib(h->ctx, 0, fib, ok) || dabx_get_state(h->ctx, 0, &st) || dabx_get_sync(h->ctx, 0, &rec)) return;
-    int good = 0;
-    for (int i = 0; i < 12; ++i)
-        if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
-    const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
-    // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy.
-    // The null symbol may carry TII carriers (32 of 1536), so its noise level is taken from the median
-    // in-band bin of its spectrum (median of an exponential distribution = mean * ln 2) rather than
-    // from its total energy; for a TII-free null the two agree.
-    bool have_null = false;
-    double noise = static_cast<double>(rec.e_null);
-    if (st.locked) {
-        h->null_power.resize(2048);
-        have_null = dabx_get_null_spectrum(h->ctx, 0, h->null_power.data()) == DABX_OK;
-        if (have_null) {
-            float band[1536];
-            std::memcpy(band, h->null_power.data() + 1, 768 * sizeof(float));
-            std::memcpy(band + 768, h->null_power.data() + 2048 - 768, 768 * sizeof(float));
-            std::nth_element(band, band + 768, band + 1536);
-            noise = static_cast<double>(band[768]) / 0.6931471805599453;
-        }
-    }
-    int16_t snr10 = 0;
-    const double sig = static_cast<double>(rec.e_sig);
-    if (noise > 0 && sig > noise) snr10 = static_cast<int16_t>(std::min(600L, std::lround(100.0 * std::log10((sig - noise) / noise))));
-    else if (sig > 0 && noise <= 0) snr10 = 600;
     if (h->db.reconfigured) {                             // multiplex reconfiguration took effect (EN 300 401 §6.5)
         h->db.reconfigured = false;
         notify(h, DABSDR_NID_RECONFIGURATION, DABSDR_NSTAT_SUCCESS, nullptr, 0);
@@ -527,8 +567,25 @@ void after_step(dabsdr_s *h)
             }
         }
         h->sel = std::move(keep);
-        apply_selections(h);
+        apply_selections_or_drop(h);
     }
+    if (h->db.eid_changed) {                              // another ensemble on this frequency (two recordings in one file,
+        h->sel.clear();                                   // a transmitter that changed its multiplex): everything known is stale
+        apply_selections_or_drop(h);
+        reset_receiver(h, DABSDR_RESET_NEW_EID);          // the host restarts on it (radiocontrol.cpp:118-127)
+        return false;
+    }
+    for (const auto &ch : h->db.apps_changed)             // FIG 0/13 changed for a running component -> the host asks for the list again
+        for (const auto &sp : h->sel)                     // (radiocontrol.cpp:214-222, 2323-2333)
+            if (sp->sid == ch.first && sp->scids == ch.second) {
+                if (const figdb::Service *sv = h->db.find_service(ch.first))
+                    for (const auto &c : sv->comp)
+                        if (c.scids == ch.second) sp->apps = c.apps;
+                dabsdrNtfUserAppUpdate_t u = {ch.first, static_cast<uint8_t>(ch.second)};
+                notify(h, DABSDR_NID_USER_APP_UPDATE, DABSDR_NSTAT_SUCCESS, &u, sizeof u);
+                break;
+            }
+    h->db.apps_changed.clear();
     for (uint32_t sid : h->db.pty_changed)                // FIG 0/17 -> DABSDR_NID_PTY (dabsdr.h:353-357)
         if (const figdb::Service *sv = h->db.find_service(sid)) {
             dabsdrNtfPTy_t p = {sid, static_cast<uint8_t>(sv->pty), static_cast<uint8_t>(sv->pty)};
@@ -546,6 +603,41 @@ void after_step(dabsdr_s *h)
         }
         notify(h, DABSDR_NID_ANNOUNCEMENT_SWITCHING, DABSDR_NSTAT_SUCCESS, &a, sizeof a);
     }
+    return true;
+}
+
+void after_step(dabsdr_s *h)
+{
+    uint8_t fib[12 * 32], ok[12];
+    dabx_stream_state_t st;
+    dabx_sync_rec_t rec;
+    if (dabx_get_fib(h->ctx, 0, fib, ok) || dabx_get_state(h->ctx, 0, &st) || dabx_get_sync(h->ctx, 0, &rec)) return;
+    int good = 0;
+    for (int i = 0; i < 12; ++i)
+        if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
+    const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
+    // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy.
+    // The null symbol may carry TII carriers (32 of 1536), so its noise level is taken from the median
+    // in-band bin of its spectrum (median of an exponential distribution = mean * ln 2) rather than
+    // from its total energy; for a TII-free null the two agree.
+    bool have_null = false;
+    double noise = static_cast<double>(rec.e_null);
+    if (st.locked) {
+        h->null_power.resize(2048);
+        have_null = dabx_get_null_spectrum(h->ctx, 0, h->null_power.data()) == DABX_OK;
+        if (have_null) {
+            float band[1536];
+            std::memcpy(band, h->null_power.data() + 1, 768 * sizeof(float));
+            std::memcpy(band + 768, h->null_power.data() + 2048 - 768, 768 * sizeof(float));
+            std::nth_element(band, band + 768, band + 1536);
+            noise = static_cast<double>(band[768]) / 0.6931471805599453;
+        }
+    }
+    int16_t snr10 = 0;
+    const double sig = static_cast<double>(rec.e_sig);
+    if (noise > 0 && sig > noise) snr10 = static_cast<int16_t>(std::min(600L, std::lround(100.0 * std::log10((sig - noise) / noise))));
+    else if (sig > 0 && noise <= 0) snr10 = 600;
+    if (!after_fibs(h)) return;
     if (lvl != h->sync_level) {
         h->sync_level = lvl;
         dabsdrNtfSyncStatus_t s = {lvl, snr10};
@@ -579,9 +671,11 @@ void after_step(dabsdr_s *h)
     if (!h->sel.empty()) {
         size_t stride = 0;
         for (const auto &sp : h->sel) stride += static_cast<size_t>(3 * sp->kbps);
-        std::vector<uint8_t> msc(4 * stride);
+        // dabx_get_msc copies 4 x the stride the CONTEXT has; it must be the one this loop slices by
+        const bool agree = stride == static_cast<size_t>(h->msc_stride);
+        std::vector<uint8_t> msc(4 * std::max(stride, static_cast<size_t>(h->msc_stride)));
         uint8_t valid[4] = {0, 0, 0, 0};
-        const bool have_msc = dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK;
+        const bool have_msc = agree && dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK;
         size_t off = 0;
         for (size_t k = 0; k < h->sel.size(); ++k) {
             Selection *sp = h->sel[k].get();
@@ -652,9 +746,16 @@ void after_step(dabsdr_s *h)
     }
 }
 
+void worker_loop(dabsdr_s *h);
 void worker_main(dabsdr_s *h)
 {
     pthread_setname_np(pthread_self(), "dabsdr");
+    struct Done { dabsdr_s *h; ~Done() { h->worker_done.store(true); } } done{h};     // also when the thread is cancelled
+    worker_loop(h);
+}
+
+void worker_loop(dabsdr_s *h)
+{
     h->fbuf.resize(2 * kPullChunk);
     h->sbuf.resize(2 * kPullChunk);
     // requests are served between input calls (every 8 ms of signal), like the reference, whose
@@ -680,6 +781,21 @@ void worker_main(dabsdr_s *h)
             if (got && !serve(false)) return;
             if (h->frequency == 0 || !h->ctx) break;
             h->input(h->fbuf.data(), static_cast<uint16_t>(kPullChunk));
+            if (!h->gain_set) {                                         // the first frame after a tune fixes the gain
+                h->first_frame.insert(h->first_frame.end(), h->fbuf.begin(), h->fbuf.end());
+                if (h->first_frame.size() < 2 * static_cast<size_t>(DABX_FRAME_SAMPLES)) continue;
+                h->gain_shift = choose_shift(h->first_frame.data(), h->first_frame.size());
+                h->gain_set = true;
+                h->frame_fill = 0; h->frame_peak = 0.0f;
+                bool ok = true;
+                for (size_t o = 0; ok && o < h->first_frame.size(); o += 2 * kPullChunk) {
+                    convert(h, h->first_frame.data() + o, h->sbuf.data(), 2 * kPullChunk);
+                    ok = dabx_push(h->ctx, 0, h->sbuf.data(), kPullChunk, 0) == DABX_OK;
+                }
+                h->first_frame.clear(); h->first_frame.shrink_to_fit();
+                if (!ok) break;
+                continue;
+            }
             convert(h, h->fbuf.data(), h->sbuf.data(), 2 * kPullChunk);
             if (dabx_push(h->ctx, 0, h->sbuf.data(), kPullChunk, 0) != DABX_OK) break;
         }
@@ -740,7 +856,15 @@ void dabsdrDeinit(dabsdrHandle_t *handle)
     dabsdr_s *h = *handle;
     h->exit_req.store(true);
     h->cv.notify_all();
-    if (h->worker.joinable()) h->worker.join();
+    if (h->worker.joinable()) {
+        // The worker may sit inside the host's input callback, which blocks until samples arrive (reference:
+        // inputdevice.cpp:70-85 waits on a condition variable).  The reference library's thread is cancelled by Deinit
+        // (radiocontrol.cpp:76 relies on it), so: a grace period, then pthread_cancel — the wait is a cancellation
+        // point.  All GPU teardown happens here, on the calling thread, after the join.
+        for (int i = 0; i < 100 && !h->worker_done.load(); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        if (!h->worker_done.load()) pthread_cancel(h->worker.native_handle());
+        h->worker.join();
+    }
     if (h->ctx) dabx_destroy(h->ctx);
     delete h;
     *handle = nullptr;
@@ -913,6 +1037,16 @@ DABSDR_API int dabsdr_amd_fig_dump(const uint8_t *fibs, int n_fibs, char *out, i
     if (static_cast<int>(s.size()) + 1 > cap) return -1;
     std::memcpy(out, s.c_str(), s.size() + 1);
     return static_cast<int>(s.size());
+}
+
+// test hook: hand FIBs (CRC already verified) to a running receiver as if its FIC had delivered them; served on the
+// library's thread like any request (tests/test_gpu_legacy_api.py: reconfiguration, ensemble change, FIG 0/13 update)
+DABSDR_API void dabsdr_amd_inject_fibs(dabsdrHandle_t h, const uint8_t *fibs, int n_fibs)
+{
+    Request r;
+    r.kind = Req::InjectFibs;
+    r.blob.assign(fibs, fibs + 32 * static_cast<size_t>(n_fibs));
+    post(h, r);
 }
 
 // test hook (CPU only): parse FIBs, then answer GetEnsemble / GetServiceList / GetServiceComponents exactly as the

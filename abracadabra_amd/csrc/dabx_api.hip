@@ -32,6 +32,12 @@ namespace {
         }                                                                                              \
     } while (0)
 
+struct DevTmp {                              // device scratch of one call: freed on every way out
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 template <class T>
 int dev_upload(T *&dst, const std::vector<T> &src)
 {
@@ -99,7 +105,7 @@ struct dabx_ctx {
     hipStream_t copy_stream = nullptr;      // DABX_SRC_PINNED pushes: overlap with the kernels of a step in flight
     hipEvent_t copy_done = nullptr;
     bool copies_queued = false;
-    size_t scratch_words = 0;
+    size_t scratch_words = 0, work_cap = 0;
     // sample-rate conversion in front of the ring (dabx_resample.hip)
     rs::State *d_rs_state = nullptr;        // [S], zeroed
     uint8_t *d_rs_in = nullptr; float *d_rs_mu = nullptr; int32_t *d_rs_seg = nullptr; float2 *d_rs_A = nullptr, *d_rs_x = nullptr;
@@ -189,8 +195,13 @@ int build_work(dabx_ctx *c, int n_frames)
     }
     if (blocks >> 32) return DABX_E_NOMEM;
     c->n_work = static_cast<int>(all.size());
-    int rc;
-    if ((rc = dev_upload(c->d_work, all))) return rc;
+    if (all.size() > c->work_cap) {                      // grows only: the one-frame legacy path alternates between sizes
+        if (c->d_work) (void)hipFree(c->d_work);
+        c->d_work = nullptr; c->work_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_work), all.size() * sizeof(DevWork)));
+        c->work_cap = all.size();
+    }
+    if (!all.empty()) HIPCHK(hipMemcpy(c->d_work, all.data(), all.size() * sizeof(DevWork), hipMemcpyHostToDevice));
     if (blocks * 64 > c->scratch_words) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         c->d_scratch = nullptr;
@@ -210,6 +221,8 @@ int build_superframe_work(dabx_ctx *c)
     const std::vector<DevSfSub> old_subs = c->sf_subs;
     const std::vector<dabx_subch_t> old_ident = c->sf_ident;
     DevSfState *old_state = c->d_sf_state;
+    DevTmp old_guard;                                                 // the previous state array goes on every way out
+    old_guard.p = old_state;
     c->sf_subs.clear();
     c->sf_ident.clear();
     c->sf_max_rec = (4 + 4 * c->cfg.max_frames) / 5;
@@ -231,10 +244,7 @@ int build_superframe_work(dabx_ctx *c)
         if (p) (void)hipFree(p);
     c->d_sf_subs = nullptr; c->d_sf_state = nullptr; c->d_sf_recs = nullptr; c->d_sf_data = nullptr;
     c->sf_dirty = false;
-    if (c->sf_subs.empty()) {
-        if (old_state) (void)hipFree(old_state);
-        return DABX_OK;
-    }
+    if (c->sf_subs.empty()) return DABX_OK;
     if (!c->d_gf) {                                                   // GF(2^8) tables: exp[512], log[256]
         std::vector<uint8_t> tab(768, 0);
         unsigned x = 1;
@@ -256,7 +266,6 @@ int build_superframe_work(dabx_ctx *c)
                 break;
             }
         }
-    if (old_state) (void)hipFree(old_state);
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_recs), static_cast<size_t>(rec) * sizeof(DevSfRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sf_data), std::max<size_t>(data, 16)));
     return DABX_OK;
@@ -301,6 +310,8 @@ const char *dabx_strerror(int code)
     }
 }
 
+static int create_body(dabx_ctx *c, const dabx_config_t *cfg);
+
 int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
 {
     if (!cfg || !out || cfg->n_streams < 1 || cfg->max_frames < 1 || cfg->max_frames > 60 ||
@@ -315,6 +326,14 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
     HIPCHK(hipSetDevice(cfg->device));
     dabx_ctx *c = new (std::nothrow) dabx_ctx;
     if (!c) return DABX_E_NOMEM;
+    const int rc = create_body(c, cfg);
+    if (rc) { dabx_destroy(c); return rc; }          // whatever had been allocated goes with it
+    *out = c;
+    return DABX_OK;
+}
+
+static int create_body(dabx_ctx *c, const dabx_config_t *cfg)
+{
     c->cfg = *cfg;
     c->bps = cfg->fmt == DABX_FMT_U8 ? 2 : 4;
     c->ti_slots = 16;
@@ -347,11 +366,9 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
     std::memset(c->h_state, 0, S * sizeof(DevState));
     c->h_sub.assign(S * 64, DevSub{});
     int rc = upload_tables(c);
-    if (rc) { dabx_destroy(c); return rc; }
+    if (rc) return rc;
     c->pool_lookup(dabx::fic_profile());                 // offset 0
-    if ((rc = dev_upload(c->d_info, c->info_pool))) { dabx_destroy(c); return rc; }
-    *out = c;
-    return DABX_OK;
+    return dev_upload(c->d_info, c->info_pool);
 }
 
 void dabx_destroy(dabx_ctx *c)
@@ -661,6 +678,7 @@ int dabx_wait(dabx_ctx *c)
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (!c->pending) return DABX_OK;
+    c->pending = false;                              // also when the synchronisation fails: the context stays usable
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int s = 0; s < c->cfg.n_streams; ++s) c->streams[s].st = c->h_state[s];
     if (c->timing) {
@@ -670,7 +688,6 @@ int dabx_wait(dabx_ctx *c)
         HIPCHK(hipEventElapsedTime(&c->last_ms[3], c->ev[5], c->ev[4]));      // k_superframe (if any) + k_finish
         HIPCHK(hipEventElapsedTime(&c->last_ms[4], c->ev[0], c->ev[4]));
     }
-    c->pending = false;
     return DABX_OK;
 }
 
@@ -772,16 +789,15 @@ int dabx_fft2048(dabx_ctx *c, const float *in, float *out, int n_vec)
     if (!c || !in || !out || n_vec < 1) return DABX_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
-    float2 *d_in = nullptr, *d_out = nullptr;
+    DevTmp t_in, t_out;
     const size_t bytes = static_cast<size_t>(n_vec) * 2048 * sizeof(float2);
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_in), bytes));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_out), bytes));
-    HIPCHK(hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fft, dim3(n_vec), dim3(256), 0, c->stream, c->dev().tab, d_in, d_out);
+    HIPCHK(hipMalloc(&t_in.p, bytes));
+    HIPCHK(hipMalloc(&t_out.p, bytes));
+    HIPCHK(hipMemcpy(t_in.p, in, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fft, dim3(n_vec), dim3(256), 0, c->stream, c->dev().tab, t_in.as<float2>(), t_out.as<float2>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in); (void)hipFree(d_out);
+    HIPCHK(hipMemcpy(out, t_out.p, bytes, hipMemcpyDeviceToHost));
     return DABX_OK;
 }
 
@@ -796,19 +812,18 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     const int nsteps = p.steps();
     const size_t words = static_cast<size_t>((nsteps / 24 + 1) * 64);
     if (nsteps % 48 != 6) return DABX_E_PROFILE;             // every DAB codeword: 48 k + 6 trellis steps
-    int8_t *d_soft = nullptr; uint32_t *d_info = nullptr, *d_scr = nullptr; uint8_t *d_out = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_soft), static_cast<size_t>(n_cw) * p.n_coded));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_info), info.size() * 4));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_scr), static_cast<size_t>(n_cw) * words * 4));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_out), static_cast<size_t>(n_cw) * (p.n_in / 8)));
-    HIPCHK(hipMemcpy(d_soft, soft, static_cast<size_t>(n_cw) * p.n_coded, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_info, info.data(), info.size() * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_viterbi_linear, dim3((n_cw + 3) / 4), dim3(256), 0, c->stream, d_soft, p.n_coded, d_info, nsteps, p.n_in,
-                       c->d_prbs, d_scr, d_out, n_cw);
+    DevTmp t_soft, t_info, t_scr, t_out;
+    HIPCHK(hipMalloc(&t_soft.p, static_cast<size_t>(n_cw) * p.n_coded + 64));
+    HIPCHK(hipMalloc(&t_info.p, info.size() * 4));
+    HIPCHK(hipMalloc(&t_scr.p, static_cast<size_t>(n_cw) * words * 4));
+    HIPCHK(hipMalloc(&t_out.p, static_cast<size_t>(n_cw) * (p.n_in / 8)));
+    HIPCHK(hipMemcpy(t_soft.p, soft, static_cast<size_t>(n_cw) * p.n_coded, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_viterbi_linear, dim3((n_cw + 3) / 4), dim3(256), 0, c->stream, t_soft.as<int8_t>(), p.n_coded, t_info.as<uint32_t>(), nsteps,
+                       p.n_in, c->d_prbs, t_scr.as<uint32_t>(), t_out.as<uint8_t>(), n_cw);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, d_out, static_cast<size_t>(n_cw) * (p.n_in / 8), hipMemcpyDeviceToHost));
-    (void)hipFree(d_soft); (void)hipFree(d_info); (void)hipFree(d_scr); (void)hipFree(d_out);
+    HIPCHK(hipMemcpy(out, t_out.p, static_cast<size_t>(n_cw) * (p.n_in / 8), hipMemcpyDeviceToHost));
     return p.n_in / 8;
 }
 
@@ -909,6 +924,8 @@ int dabx_rawfile_probe(const uint8_t *head, int n_bytes, dabx_rawfile_info_t *in
 int dabx_enable_timing(dabx_ctx *c, int on)
 {
     if (!c) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->pending) return DABX_E_ARG;
     c->timing = on != 0;
     return DABX_OK;
 }

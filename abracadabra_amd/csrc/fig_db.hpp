@@ -91,6 +91,11 @@ public:
     std::map<int, AnnouncementSwitch> switching;      // FIG 0/19 by cluster id
     std::vector<uint32_t> pty_changed;                // SIds whose PTy changed since the owner last looked
     bool switching_changed = false;
+    std::vector<std::pair<uint32_t, int>> apps_changed;   // (SId, SCIdS) whose FIG 0/13 user applications changed
+    // FIG 0/0 announcing another ensemble than the one in this database (two FIBs in a row, so that one damaged FIB with
+    // a matching CRC cannot do it): the owner resets (reference: DABSDR_RESET_NEW_EID, dabsdr.h; radiocontrol.cpp:118-127)
+    bool eid_changed = false;
+    int eid_candidate = -1, eid_candidate_count = 0;
     int fibs_seen = 0;
     // multiplex reconfiguration (EN 300 401 §6.5): FIGs of the multiplex configuration sent with C/N = 1 describe the
     // NEXT configuration; FIG 0/0 announces the change and the CIF count at which it takes effect
@@ -151,7 +156,15 @@ private:
         switch (ext) {
         case 0:
             if (n >= 4) {
-                ens.eid = (p[0] << 8) | p[1];
+                const int eid_now = (p[0] << 8) | p[1];
+                if (ens.eid >= 0 && eid_now != ens.eid) {
+                    eid_candidate_count = eid_now == eid_candidate ? eid_candidate_count + 1 : 1;
+                    eid_candidate = eid_now;
+                    if (eid_candidate_count >= 2) eid_changed = true;
+                    break;                            // nothing of the other ensemble goes into this database
+                }
+                eid_candidate_count = 0;
+                ens.eid = eid_now;
                 ens.alarm = (p[2] >> 5) & 1;
                 ens.cif_count = (p[2] & 0x1F) * 250 + p[3];
                 const bool change = (p[2] >> 6) != 0;
@@ -307,7 +320,11 @@ private:
                 auto it = services.find(sid);
                 if (it != services.end())
                     for (auto &c : it->second.comp)
-                        if (c.scids == scids) c.apps = apps;
+                        if (c.scids == scids) {
+                            bool same = c.apps.size() == apps.size();
+                            for (size_t i = 0; same && i < apps.size(); ++i) same = c.apps[i].type == apps[i].type && c.apps[i].data == apps[i].data;
+                            if (!same) { c.apps = apps; apps_changed.emplace_back(sid, scids); }
+                        }
             }
             break;
         case 14:                      // FEC sub-channel organisation (packet mode)
