@@ -12,7 +12,8 @@
 // No MFMA: the FFT is LDS-exchange bound, the Viterbi is VALU/DPP bound.
 //
 // Arithmetic contract: every float operation below is one IEEE
-// binary32 operation in a fixed order; the file is compiled with
+// binary32 operation in a fixed order — a fused multiply-add only where it is
+// written out (the complex products); the file is compiled with
 // -ffp-contract=off so results equal the CPU checker bit for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,15 +34,17 @@ constexpr int TI_SEG = CIFBITS / 16;   // bytes per residue class in a residue-m
 
 struct cf { float r, i; };
 
+// complex products: one rounded product, then one fused multiply-add (2 + 2 instructions instead of 4 + 2) —
+// the same two operations, in the same roles, in the CPU checker (oracle/dab_rx.c: fmaf)
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
-    float p0 = a.r * b.r, p1 = a.i * b.i, p2 = a.r * b.i, p3 = a.i * b.r;
-    return {p0 - p1, p2 + p3};
+    const float p1 = a.i * b.i, p3 = a.i * b.r;
+    return {__builtin_fmaf(a.r, b.r, -p1), __builtin_fmaf(a.r, b.i, p3)};
 }
 __device__ __forceinline__ cf cmulc(cf a, cf b)   // a * conj(b)
 {
-    float p0 = a.r * b.r, p1 = a.i * b.i, p2 = a.i * b.r, p3 = a.r * b.i;
-    return {p0 + p1, p2 - p3};
+    const float p1 = a.i * b.i, p3 = a.r * b.i;
+    return {__builtin_fmaf(a.r, b.r, p1), __builtin_fmaf(a.i, b.r, -p3)};
 }
 __device__ __forceinline__ cf rotq(cf x, int q)   // x * exp(-j q pi/2), exact
 {

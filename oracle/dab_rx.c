@@ -12,9 +12,10 @@
  * source, test or golden vector to follow, and the binary is not executed.
  * The bit-level rules follow ETSI EN 300 401; the arithmetic contract (what
  * "bit-exact" means for the float stages) is fixed in DESIGN.md §3: every
- * float operation is a single IEEE-754 binary32 operation (no FMA
- * contraction) in a stated order, so a GPU and a CPU evaluation agree bit for
- * bit.  Build with -ffp-contract=off.
+ * float operation is a single IEEE-754 binary32 operation in a stated order
+ * (a fused multiply-add only where fmaf() is written out: the complex
+ * products), so a GPU and a CPU evaluation agree bit for bit.  Build with
+ * -ffp-contract=off; -mfma makes fmaf() one instruction where the CPU has it.
  */
 #include "dab_spec.h"
 #include <math.h>
@@ -79,15 +80,19 @@ static void tables_init(void)
 }
 
 /* ----------------------------------------------------- arithmetic contract */
+/* complex products: one rounded product, then one fused multiply-add, the same two operations in the same roles as
+ * the kernels' cmul / cmulc (abracadabra_amd/csrc/dabx_kernels.hip) */
 static inline void cmul(float ar, float ai, float br, float bi, float *yr, float *yi)
 {
-    float p0 = ar * br, p1 = ai * bi, p2 = ar * bi, p3 = ai * br;
-    *yr = p0 - p1; *yi = p2 + p3;
+    float p1 = ai * bi, p3 = ai * br;
+    float r = fmaf(ar, br, -p1), i = fmaf(ar, bi, p3);
+    *yr = r; *yi = i;
 }
 static inline void cmulc(float ar, float ai, float br, float bi, float *yr, float *yi)
 {   /* a * conj(b) */
-    float p0 = ar * br, p1 = ai * bi, p2 = ai * br, p3 = ar * bi;
-    *yr = p0 + p1; *yi = p2 - p3;
+    float p1 = ai * bi, p3 = ar * bi;
+    float r = fmaf(ar, br, p1), i = fmaf(ai, br, -p3);
+    *yr = r; *yi = i;
 }
 /* multiply by exp(-j q pi/2): exact */
 static inline void rotq(float xr, float xi, int q, float *yr, float *yi)

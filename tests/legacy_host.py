@@ -13,13 +13,14 @@ TF = 196608
 
 
 class LegacyHost:
-    def __init__(self, samples_f32, gate_at=None):
+    def __init__(self, samples_f32, gate_at=None, gate_on_new_eid=False):
         """samples_f32: interleaved I,Q floats the input callback hands out (zeros after the end, like a flushed FIFO).
         gate_at: sample count (complex) after which the input blocks until open_gate() (the library is un-paced)."""
         self.L = aa.load_library()
         self.samples = np.ascontiguousarray(samples_f32, dtype=np.float32)
         self.pos = 0
         self.gate_at = gate_at
+        self.gate_on_new_eid = gate_on_new_eid      # hold the input from RESET(NEW_EID) on until open_gate(): the host's restart takes time
         self.gate = threading.Event()
         self.events, self.lock = [], threading.Lock()
         self.handle = C.c_void_p()
@@ -43,6 +44,8 @@ class LegacyHost:
                 rec["freq"] = C.cast(n.pData, C.POINTER(C.c_uint32)).contents.value
             elif n.nid == NID["RESET"]:
                 rec["flag"] = C.cast(n.pData, C.POINTER(C.c_int)).contents.value
+                if rec["flag"] == 1 and self.gate_on_new_eid:
+                    self.gate_at = self.pos // 2
             elif n.nid == NID["SYNC_STATUS"]:
                 rec["level"] = C.cast(n.pData, C.POINTER(C.c_int)).contents.value
                 rec["snr10"] = C.cast(n.pData + 4, C.POINTER(C.c_int16)).contents.value
