@@ -654,15 +654,18 @@ struct VitSrc {
 // MSC rows are stored residue-major (TI_SEG = 55296/16 bytes per residue class of the bit
 // index): logical frame r takes exactly one residue class from each of 16 rows, so this
 // layout makes every (row, residue) read contiguous instead of one byte per 16.
-
-// byte offset (from src.base) of coded bit i of the codeword
-__device__ __forceinline__ uint32_t soft_off(const VitSrc &src, uint32_t i)
+//
+// Byte offset (from src.base) of coded bit i of the codeword = tab[i & 15] + ((i >> 4) << sh): the 16 residue
+// classes of a codeword start at 16 fixed places.  Time de-interleaved: class k lives in row (r + bitrev4(k)) of the
+// ring, at k * TI_SEG inside it (sub-channels start on 64-bit boundaries, so base already points at start_bit >> 4),
+// consecutive members one byte apart (sh = 0).  Linear (FIC, stage tests): tab[k] = k, members 16 bytes apart (sh = 4).
+// The wave keeps the table in LDS: an address costs and / shift / read / shift-add instead of nine instructions.
+__device__ __forceinline__ uint32_t soft_tab_entry(const VitSrc &src, uint32_t k)
 {
-    if (src.slot_mask < 0) return i;
-    uint32_t d = __builtin_bitreverse32(i) >> 28;              // delay of bit i: bit-reversed (i mod 16)
-    // sub-channels start on 64-bit boundaries, so base already points at (start_bit >> 4).  The offset
-    // stays below 2^32 (at most 64 rows of 55296 bytes): 24-bit multiplies, scalar base + vector offset
-    return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(i & 15u, (uint32_t)TI_SEG) + (i >> 4);
+    if (src.slot_mask < 0) return k;
+    const uint32_t d = __builtin_bitreverse32(k) >> 28;            // delay of residue class k: bit-reversed k
+    // the offset stays below 2^32 (at most 64 rows of 55296 bytes): 24-bit multiplies
+    return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(k, (uint32_t)TI_SEG);
 }
 
 // depuncturing word of trellis step tau (0 = past the end: nothing to fetch)
@@ -670,15 +673,18 @@ __device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info,
 {
     return tau < nsteps ? info[tau] : 0u;
 }
-// packed soft values (x0 in byte 0) of the step described by w, zero where punctured
-__device__ __forceinline__ int gather_step(const VitSrc &src, uint32_t w)
+// packed soft values (x0 in byte 0) of the step described by w, zero where punctured.  The four loads are
+// unconditional (a punctured position re-reads the next kept bit, a valid address) and issued together, so no
+// branch and no wait sits between them; the keep mask is applied to the bytes afterwards.
+__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
 {
-    uint32_t off = w >> 4;
-    int b[4] = {0, 0, 0, 0};                       // the (up to) four loads are issued before any result is used
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (w & (8u >> j)) { b[j] = (int)reinterpret_cast<const uint8_t *>(src.base)[soft_off(src, off)]; ++off; }
-    return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    const uint32_t k0 = (w >> 3) & 1u, k1 = (w >> 2) & 1u, k2 = (w >> 1) & 1u, k3 = w & 1u;
+    const uint32_t i0 = w >> 4, i1 = i0 + k0, i2 = i1 + k1, i3 = i2 + k2;
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(src.base);
+    const uint32_t a0 = tab[i0 & 15u] + ((i0 >> 4) << sh), a1 = tab[i1 & 15u] + ((i1 >> 4) << sh);
+    const uint32_t a2 = tab[i2 & 15u] + ((i2 >> 4) << sh), a3 = tab[i3 & 15u] + ((i3 >> 4) << sh);
+    const uint32_t b0 = base[a0], b1 = base[a1], b2 = base[a2], b3 = base[a3];
+    return (int)((b0 & (0u - k0)) | ((b1 & (0u - k1)) << 8) | ((b2 & (0u - k2)) << 16) | ((b3 & (0u - k3)) << 24));
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
@@ -789,7 +795,7 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging buffer in LDS: [2 blocks][64 dwords]
+//   xs:     the wave's soft-value staging buffer in LDS: [2 blocks][64 dwords], then the 16 dwords of the address table
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
@@ -819,12 +825,15 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     // dependent loads has a whole block of ACS work to hide behind.
     const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 48..63 fetch nothing
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);   // LDS byte address (the low 32 bits of a shared pointer)
-    int xnext = gather_step(src, step_word(info, tl, nsteps));
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 128;
+    const int sh = src.slot_mask < 0 ? 4 : 0;
+    if (lane < 16) xs[128 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
+    int xnext = gather_step(src, tab, sh, step_word(info, tl, nsteps));
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
         xs[(blk & 1) * 64 + lane] = xnext;                       // lanes 48..63 write padding
-        xnext = gather_step(src, wnext);
+        xnext = gather_step(src, tab, sh, wnext);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
         const uint32_t va = va0 + (uint32_t)((blk & 1) * 256);
         uint32_t bits = 0;
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][128];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][144];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     int *xs = xs_all[wave];
     uint32_t *ring = ring_all[wave];
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][128];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][144];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
