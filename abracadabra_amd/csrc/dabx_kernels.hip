@@ -24,7 +24,8 @@ namespace {
 constexpr int TF = 196608, TNULL = 2656, TS = 2552, TU = 2048, TG = 504;
 constexpr int NSYM = 76, SYMBITS = 3072, NCAR = 1536;
 constexpr int FICBITS = 9216, CIFBITS = 55296;
-constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 17, PM_INIT = -1000000;
+constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 16, PM_INIT = -1000000;
+constexpr float SOFT_MAX = 63.0f;          // soft bits are limited to +-63: the sum of two fits a byte (k_viterbi packs x0 + x3)
 constexpr float LOCK_THR = 48.0f;
 constexpr int EARLY_SPAN = 400;            // the first path may lead the strongest one by up to this many samples ...
 constexpr float EARLY_THR = 0.125f;        // ... if it carries at least this fraction of its power (-9 dB)
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             for (int e = 0; e < 8; ++e)
                 if (nidx[e] >= 0) {
                     float a = rintf(y[e].r * gsc), b = rintf(y[e].i * gsc);
-                    a = __builtin_amdgcn_fmed3f(a, -127.0f, 127.0f); b = __builtin_amdgcn_fmed3f(b, -127.0f, 127.0f);   // clamp in one instruction
+                    a = __builtin_amdgcn_fmed3f(a, -SOFT_MAX, SOFT_MAX); b = __builtin_amdgcn_fmed3f(b, -SOFT_MAX, SOFT_MAX);   // clamp in one instruction
                     soft[nidx[e]] = (int8_t)a;
                     soft[nidx[e] + imoff] = (int8_t)b;
                 }
@@ -673,50 +674,54 @@ __device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info,
 {
     return tau < nsteps ? info[tau] : 0u;
 }
-// packed soft values (x0 in byte 0) of the step described by w, zero where punctured.  The four loads are
-// unconditional (a punctured position re-reads the next kept bit, a valid address) and issued together, so no
-// branch and no wait sits between them; the keep mask is applied to the bytes afterwards.
-__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
+// The soft values of the step described by w as the two A rows the matrix core wants: keep = (x0 + x3, x1, x2, 1),
+// send = (-(x0 + x3), -x1, -x2, 0), one byte each, zero where punctured.  x0 and x3 belong to the same generator
+// polynomial and |x| <= 63, so their sum fits a byte.  The four loads are unconditional (a punctured position re-reads
+// the next kept bit, a valid address) and issued together, so no branch and no wait sits between them.
+__device__ __forceinline__ void gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w, int &keep, int &send)
 {
     const uint32_t k0 = (w >> 3) & 1u, k1 = (w >> 2) & 1u, k2 = (w >> 1) & 1u, k3 = w & 1u;
     const uint32_t i0 = w >> 4, i1 = i0 + k0, i2 = i1 + k1, i3 = i2 + k2;
-    const uint8_t *base = reinterpret_cast<const uint8_t *>(src.base);
+    const int8_t *base = src.base;
     const uint32_t a0 = tab[i0 & 15u] + ((i0 >> 4) << sh), a1 = tab[i1 & 15u] + ((i1 >> 4) << sh);
     const uint32_t a2 = tab[i2 & 15u] + ((i2 >> 4) << sh), a3 = tab[i3 & 15u] + ((i3 >> 4) << sh);
-    const uint32_t b0 = base[a0], b1 = base[a1], b2 = base[a2], b3 = base[a3];
-    return (int)((b0 & (0u - k0)) | ((b1 & (0u - k1)) << 8) | ((b2 & (0u - k2)) << 16) | ((b3 & (0u - k3)) << 24));
+    const int b0 = base[a0], b1 = base[a1], b2 = base[a2], b3 = base[a3];
+    const int x03 = (b0 & (0 - (int)k0)) + (b3 & (0 - (int)k3)), x1 = b1 & (0 - (int)k1), x2 = b2 & (0 - (int)k2);
+    keep = (x03 & 0xff) | ((x1 & 0xff) << 8) | ((x2 & 0xff) << 16) | (1 << 24);
+    send = ((0 - x03) & 0xff) | (((0 - x1) & 0xff) << 8) | (((0 - x2) & 0xff) << 16);
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
 // Path metrics are scaled by 64, so their low six bits are free: they carry the keep(1)/receive(0) tags of the last
-// (up to) six steps of the lane's SURVIVOR — the tags travel with the path through the max.  Per step, 4 VALU issues:
+// (up to) six steps of the lane's SURVIVOR — the tags travel with the path through the max.  Per step, 3 VALU issues:
 //   S = pm - 64 M                 (M = +-x0 +-x1 +-x2 +-x3, the branch metric of the lane's state)
-//   T = pm | (1 << ph)            tag "kept at phase ph"
-//   K = T + 64 M
+//   K = pm + 64 M + (1 << ph)     tag "kept at phase ph"; the bit is clear in pm, so the add sets it
 //   pm' = max(K, S of the butterfly partner lane)
 // After the six steps of a group (phases 0..5) the low six bits of a lane's metric are the history of ITS survivor
 // over those six steps; they are shifted into the lane's decision word (v_alignbit) and cleared.  A metric tie keeps
 // the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag bits are still zero.
-// Range: |metric| <= 27654 steps x 4 x 127 x 64 < 2^31.
-// The 64 M of 24 steps come from six v_mfma_i32_4x4x4_16b_i8 (one per phase, see tools/gen_acs32.py): the matrix
-// core is otherwise idle and the vector ALU is what bounds this kernel.  Their A operands are the packed soft values
-// of the chunk, staged in LDS memory by the lanes that gathered them: lane l reads step ph + 6 (l mod 4).
+// Range: |metric| <= 27654 steps x 4 x 63 x 64 < 2^31.
+// Both 64 M + tag and -64 M come from the matrix core: six v_mfma_i32_4x4x4_16b_i8 per 12 steps (one per phase, see
+// tools/gen_acs32.py), otherwise idle, while the vector ALU is what bounds this kernel.  Their A operands are the
+// packed soft values of the chunk, staged in LDS memory by the lanes that gathered them (keep rows and send rows):
+// lane l reads row l mod 4.
 #include "dabx_acs32.inc"
 #define DABX_ACS_OPS                                                                                                \
-    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [T] "=&v"(T), [D] "=&v"(D)                      \
+    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D)                                    \
     : [va] "v"(va), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),                          \
       [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5])                                                             \
     : "memory", DABX_ACS_CLOBBER
-// one chunk: four groups = 24 steps; va = LDS byte address of the chunk's first soft-value dword + 24 (lane mod 4)
-__device__ __forceinline__ void acs24(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
+// two groups = 12 steps; va = LDS byte address of the lane's A row: the chunk's first keep dword + 24 (lane & 1)
+// + (the send plane's offset if lane & 2)
+__device__ __forceinline__ void acs12(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
-    int S, K, T, D;
-    asm volatile(DABX_ACS24_TEXT DABX_ACS_OPS);
+    int S, K, D;
+    asm volatile(DABX_ACS12_TEXT DABX_ACS_OPS);
 }
 // one group of six steps (the tail of a codeword)
 __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
-    int S, K, T, D;
+    int S, K, D;
     asm volatile(DABX_ACS6_TEXT DABX_ACS_OPS);
 }
 #undef DABX_ACS_OPS
@@ -795,7 +800,7 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging buffer in LDS: [2 blocks][64 dwords], then the 16 dwords of the address table
+//   xs:     the wave's soft-value staging buffer in LDS: [keep, send][64 dwords], then the 16 dwords of the address table
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
@@ -808,11 +813,11 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         for (int i = 0; i < 6; ++i) st |= lane_coord(lane, (i + ph) % 6) << i;
         int u = st & 1, o = conv_out0(st), kg = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 3; ++j) {                      // x3 rides with x0: the same generator polynomial
             int neg = ((o >> (3 - j)) & 1) ^ u;
             kg |= (neg ? 0xC0 : 0x40) << (8 * j);          // -+64
         }
-        sk[ph] = kg;
+        sk[ph] = kg | ((1 << ph) << 24);                   // fourth column: the tag of the phase
     }
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
@@ -824,28 +829,34 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
     const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 48..63 fetch nothing
-    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);   // LDS byte address (the low 32 bits of a shared pointer)
+    // A row of this lane: rows 0, 1 = keep of steps ph, ph + 6; rows 2, 3 = send of the same steps (LDS byte address:
+    // the low 32 bits of a shared pointer)
+    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 1) + 256u * ((lane >> 1) & 1);
     const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 128;
     const int sh = src.slot_mask < 0 ? 4 : 0;
     if (lane < 16) xs[128 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
-    int xnext = gather_step(src, tab, sh, step_word(info, tl, nsteps));
+    int xk, xs_;
+    gather_step(src, tab, sh, step_word(info, tl, nsteps), xk, xs_);
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
-        xs[(blk & 1) * 64 + lane] = xnext;                       // lanes 48..63 write padding
-        xnext = gather_step(src, tab, sh, wnext);
+        xs[lane] = xk;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
+        xs[64 + lane] = xs_;                                     // operations execute in order, the previous block's reads are done
+        gather_step(src, tab, sh, wnext, xk, xs_);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
-        const uint32_t va = va0 + (uint32_t)((blk & 1) * 256);
+        const uint32_t va = va0;
         uint32_t bits = 0;
         if (blk == nblk) {                                       // the six tail steps: no output, from state 0 (lane 0)
             acs6(pm, sk, va, lane_x32, bits);
             A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
             break;
         }
-        acs24(pm, sk, va, lane_x32, bits);
+        acs12(pm, sk, va, lane_x32, bits);
+        acs12(pm, sk, va + 48u, lane_x32, bits);
         ring[((2 * blk) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
         bits = 0;
-        acs24(pm, sk, va + 96u, lane_x32, bits);
+        acs12(pm, sk, va + 96u, lane_x32, bits);
+        acs12(pm, sk, va + 144u, lane_x32, bits);
         ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;

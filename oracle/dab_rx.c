@@ -25,7 +25,8 @@
 #define NFFT 2048
 #define BACKOFF 24          /* FFT window starts this many samples inside the guard */
 #define MW 16               /* integer carrier-offset search range (kHz)            */
-#define SOFT_EXP 17         /* soft-bit scale exponent, see demap()                 */
+#define SOFT_EXP 16         /* soft-bit scale exponent, see demap()                 */
+#define SOFT_MAX 63.0f      /* soft bits are limited to +-63: the sum of two fits a byte (the GPU packs x0 + x3) */
 #define PM_INIT (-1000000)  /* path metric of states other than 0 at trellis start  */
 #define LOCK_THR 48.0f
 #define EARLY_SPAN 400      /* the first path may lead the strongest one by up to this many samples ...   */
@@ -533,8 +534,8 @@ static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *f
                 int n = T.n_of_bin[T.bin_of_pos[p]];
                 if (n < 0) continue;
                 float a = rintf(yr[p] * g), b = rintf(yi[p] * g);
-                a = a > 127.0f ? 127.0f : (a < -127.0f ? -127.0f : a);
-                b = b > 127.0f ? 127.0f : (b < -127.0f ? -127.0f : b);
+                a = a > SOFT_MAX ? SOFT_MAX : (a < -SOFT_MAX ? -SOFT_MAX : a);
+                b = b > SOFT_MAX ? SOFT_MAX : (b < -SOFT_MAX ? -SOFT_MAX : b);
                 dst[n] = (int8_t)a; dst[n + DAB_K] = (int8_t)b;
             }
         }

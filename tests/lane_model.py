@@ -41,47 +41,55 @@ def sig_tables():
 
 
 def decode(x4):
-    """x4: [nsteps, 4] int soft values (0 = punctured), nsteps a multiple of 6.  Returns decoded bits [nsteps].
+    """x4: [nsteps, 4] int soft values (0 = punctured, |x| <= 63), nsteps a multiple of 6.  Returns decoded bits [nsteps].
 
     Mirrors viterbi_wave(): path metrics are scaled by 64 and the low six bits of a metric carry the keep/receive
     tags of the last (up to) six steps of ITS survivor path (bit ph = 1: kept at the step of phase ph), so the tags
-    travel with the path through the max.  At the end of a group of six steps the six tags of every lane go into
-    the lane's decision word (five groups = 30 steps per 32-bit word, newest on top) and are cleared.  A tie keeps
-    the own path: the kept candidate has its tag bit set, the received one does not, all higher tag bits are zero.
-    The traceback then walks six steps per look-up: position ^= ~tags."""
+    travel with the path through the max.  Both candidates come straight from the matrix core: with the soft values
+    packed as (x0 + x3, x1, x2, 1) — generators 0 and 3 of the DAB mother code are the same polynomial, and the sum
+    fits a byte because |x| <= 63 — and the lane's signs as (+-64, +-64, +-64, 1 << ph), the keep row gives
+    64 M + tag and the row with the negated soft values and a 0 in the last column gives -64 M.  At the end of a
+    group of six steps the six tags go into the lane's decision word (four groups = 24 steps per word) and are
+    cleared.  A tie keeps the own path: the kept candidate has its tag bit set, the received one does not, all
+    higher tag bits are zero.  The traceback walks six steps per look-up: position ^= ~tags."""
     nsteps = len(x4)
-    assert nsteps % 6 == 0
+    assert nsteps % 6 == 0 and np.abs(x4).max(initial=0) <= 63
     sig = sig_tables()
+    assert np.array_equal(sig[:, :, 0], sig[:, :, 3])                  # x0 and x3: the same generator (133 octal)
     lanes = np.arange(64)
     coordA = lanes ^ (((lanes >> 2) & 1) * 3)
     pm = np.full(64, PM_INIT * 64, dtype=np.int64)
     pm[0] = 0
     G = nsteps // 6
-    nwords = (G + 4) // 5
+    nwords = (G + 3) // 4
     dec = np.zeros((nwords, 64), dtype=np.uint64)
     for w in range(nwords):
-        ng = min(5, G - 5 * w)
+        ng = min(4, G - 4 * w)
         bits = np.zeros(64, dtype=np.uint64)
         for gi in range(ng):
             for ph in range(6):
-                t = (5 * w + gi) * 6 + ph
-                m = 64 * (sig[ph] @ x4[t].astype(np.int64))
-                keep = (pm | (1 << ph)) + m
-                send = pm - m
+                t = (4 * w + gi) * 6 + ph
+                x = x4[t].astype(np.int64)
+                a_keep = np.array([x[0] + x[3], x[1], x[2], 1])        # MFMA A rows (int8 each)
+                a_send = np.array([-(x[0] + x[3]), -x[1], -x[2], 0])
+                assert np.abs(a_keep).max() <= 127
+                b = np.concatenate([64 * sig[ph][:, :3], np.full((64, 1), 1 << ph)], axis=1)   # MFMA B column of every lane
+                keep = pm + b @ a_keep
+                send = pm + b @ a_send
                 recv = send[lanes ^ XV[ph]]
                 pm = np.maximum(keep, recv)
                 assert np.abs(pm).max() < 2 ** 31
             bits = (((pm & 63).astype(np.uint64)) << np.uint64(26)) | (bits >> np.uint64(6))     # v_alignbit_b32 bits, pm, bits, 6
             pm = pm & ~63
-        bits >>= np.uint64(6 * (5 - ng))
+        bits >>= np.uint64(30 - 6 * ng)
         dec[w, coordA] = bits
     out = np.zeros(nsteps, dtype=np.uint8)
     A = 0
     for w in range(nwords - 1, -1, -1):
-        ng = min(5, G - 5 * w)
+        ng = min(4, G - 4 * w)
         for gi in range(ng - 1, -1, -1):
             h = (int(dec[w, A]) >> (2 + 6 * gi)) & 63
             for q in range(6):
-                out[(5 * w + gi) * 6 + q] = (A >> q) & 1
+                out[(4 * w + gi) * 6 + q] = (A >> q) & 1
             A ^= (~h) & 63
     return out
