@@ -1,8 +1,9 @@
 """Randomised GPU-vs-oracle soak (run by hand through gpurun, not collected by pytest):
     python tests/gpu_soak.py [n_scenarios] [seed]
-Every scenario draws sub-channel layouts (EEP A/B, UEP), formats, SNRs down to where the Viterbi decoder and the RS
-decoder have real work, DAB+ payloads with planted byte errors, odd step sizes — and compares every output of the HIP
-path with the oracle bit for bit."""
+Every scenario draws sub-channel layouts (EEP A/B, UEP, now and then one sub-channel that fills the multiplex), formats,
+SNRs down to where the Viterbi decoder and the RS decoder have real work, channel impairments (sampling-clock offset, a
+second path, DC offset), a blanked stretch of samples (erased soft bits: survivors that do not merge, lock loss), DAB+
+payloads with planted byte errors, odd step sizes — and compares every output of the HIP path with the oracle bit for bit."""
 import sys
 import time
 
@@ -14,6 +15,14 @@ from oracle import binding as ob                 # noqa: E402
 
 
 def layout(rng):
+    if rng.random() < 0.1:                       # one long codeword: up to 27 654 trellis steps
+        while True:
+            cand = [0, 0, int(rng.integers(1, 5)), int(rng.choice([384, 576, 768, 1152]))]
+            try:
+                if ob.any_profile(cand[1], cand[2], cand[3]).n_cu <= 864:
+                    return [cand]
+            except ValueError:
+                pass
     subs, cu = [], 0
     for _ in range(int(rng.integers(1, 7))):
         kind = rng.integers(0, 3)
@@ -56,9 +65,20 @@ def scenario(k, rng):
             else:
                 cols.append(rng.integers(0, 256, (4 * n_frames, 3 * kb), dtype=np.uint8))
         payload = np.concatenate(cols, axis=1)
-        snr = float(rng.choice([5.0, 7.0, 9.0, 12.0, 20.0]))
+        snr = float(rng.choice([3.0, 5.0, 7.0, 9.0, 12.0, 20.0]))
+        imp = {}
+        if rng.random() < 0.4:
+            imp["sco_ppm"] = float(rng.uniform(-150.0, 150.0))
+        if rng.random() < 0.4:
+            imp["echo"] = (int(rng.integers(10, 450)), float(rng.uniform(-2.0, 12.0)), float(rng.uniform(0.0, 6.28)))
+        if rng.random() < 0.4:
+            imp["dc"] = (float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8))) if fmt == 0 else (float(rng.uniform(-500, 500)), float(rng.uniform(-500, 500)))
         iq, _, _ = ob.tx_generate(seed=int(rng.integers(1 << 30)), n_frames=n_frames, subch=subs, delay=int(rng.integers(0, 150000)),
-                                  snr_db=snr, cfo_hz=float(rng.uniform(-3500, 3500)), fmt=fmt, rms=28.0 if fmt == 0 else 3000.0, payload=payload)
+                                  snr_db=snr, cfo_hz=float(rng.uniform(-3500, 3500)), fmt=fmt, rms=28.0 if fmt == 0 else 3000.0, payload=payload, **imp)
+        if rng.random() < 0.3:                   # a blanked stretch: up to 1.5 frames of silence somewhere
+            a = int(rng.integers(0, iq.size // 2 - 1000))
+            b = min(iq.size // 2, a + int(rng.integers(500, 300000)))
+            iq[2 * a:2 * b] = 128 if fmt == 0 else 0
         ctx.set_subchannels(s, subs)
         mask = sum(1 << i for i, p in enumerate(plus) if p)
         if mask:
@@ -75,6 +95,7 @@ def scenario(k, rng):
             o = orc.process(F)
             assert o["rc"] in (0, F), (k, "rc")
             assert np.array_equal(ctx.sync(s), o["sync"]), (k, step, s, "sync")
+            assert ctx.state(s)["slope"] == orc.state()["slope"] and ctx.state(s)["pos"] == orc.state()["pos"], (k, step, s, "state")
             gf, gok = ctx.fib(s)
             assert np.array_equal(gok, o["fib_ok"]), (k, step, s, "fib_ok")
             if o["rc"]:
