@@ -614,7 +614,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 // crossbar (ds_swizzle / ds_bpermute), none touches LDS memory.
 namespace {
 
-constexpr int XV[6] = {1, 2, 7, 8, 16, 32};
+// (the xor vectors of the six phases: 1, 2, 7, 8, 16, 32 — quad_perm, quad_perm, row_half_mirror, row_ror:8 as DPP
+// modifiers of the max, swap-16 and xor-32 through ds_swizzle / ds_bpermute; see tools/gen_acs32.py)
 
 // coordinates of a lane in the basis XV: a0 = b0^b2, a1 = b1^b2, a2..a5 = b2..b5
 __device__ __forceinline__ int lane_coord(int lane, int k)
@@ -633,17 +634,6 @@ __device__ __forceinline__ int conv_out0(int state)
 #pragma unroll
     for (int k = 0; k < 4; ++k) o = (o << 1) | (__popc(state & g[k]) & 1);
     return o;
-}
-
-template <int PH>
-__device__ __forceinline__ int exchange(int v, int lane)
-{
-    if (PH == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]  (xor 1)
-    if (PH == 1) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]  (xor 2)
-    if (PH == 2) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);   // row_half_mirror      (xor 7)
-    if (PH == 3) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);   // row_ror:8            (xor 8)
-    if (PH == 4) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                // swap 16 via LDS crossbar
-    return __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v);                  // xor 32
 }
 
 struct VitSrc {
