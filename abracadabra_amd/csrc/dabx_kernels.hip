@@ -520,10 +520,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
 // ------------------------------------------------------------------------ demod
 // One workgroup per (stream, frame, group of 19 symbols).  The previous symbol's
 // spectrum stays in registers (same thread owns the same bins in every symbol).
-#ifndef DEMOD_G
-#define DEMOD_G 4
-#endif
-constexpr int DEMOD_GROUPS = DEMOD_G, DEMOD_GSYMS = 76 / DEMOD_G;
+constexpr int DEMOD_GROUPS = 4, DEMOD_GSYMS = 19;          // (2 x 38 and 1 x 76 symbols per workgroup run at the same speed)
 
 template <int FMT>
 __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
