@@ -112,6 +112,11 @@ struct dabx_ctx {
     size_t rs_in_cap = 0, rs_mu_cap = 0, rs_seg_cap = 0, rs_A_cap = 0;
     std::mutex mu;
 
+    // bytes per stream in d_ring: the ring itself plus a mirror of its first DABX_RING_MIRROR samples behind its end, so
+    // that a 2048-sample FFT window never has to wrap (kernels read it with a scalar base + immediate offsets)
+    size_t stride() const { return (static_cast<size_t>(cfg.ring_samples) + DABX_RING_MIRROR) * bps; }
+    uint8_t *ring_of(int s) const { return d_ring + static_cast<size_t>(s) * stride(); }
+
     DevCtx dev() const
     {
         DevCtx c = {};
@@ -119,7 +124,7 @@ struct dabx_ctx {
         c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
         c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
         c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
-        c.ring_len = cfg.ring_samples; c.ring_bytes = static_cast<size_t>(cfg.ring_samples) * bps;
+        c.ring_len = cfg.ring_samples; c.ring_bytes = stride();
         c.n_streams = cfg.n_streams; c.max_frames = cfg.max_frames; c.ti_slots = ti_slots;
         c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0;
         return c;
@@ -349,8 +354,8 @@ static int create_body(dabx_ctx *c, const dabx_config_t *cfg)
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
-    ALLOC(c->d_ring, S * static_cast<size_t>(cfg->ring_samples) * c->bps);
-    if (cfg->fmt == DABX_FMT_U8) HIPCHK(hipMemset(c->d_ring, 128, S * static_cast<size_t>(cfg->ring_samples) * c->bps));
+    ALLOC(c->d_ring, S * c->stride());
+    if (cfg->fmt == DABX_FMT_U8) HIPCHK(hipMemset(c->d_ring, 128, S * c->stride()));
     ALLOC(c->d_state, S * sizeof(DevState));
     ALLOC(c->d_sync, S * F * sizeof(DevSync));
     ALLOC(c->d_fic, S * F * DABX_FIC_SOFT_BITS + 64);
@@ -429,14 +434,16 @@ int dabx_push(dabx_ctx *c, int s, const void *src, int64_t n, int kind)
     // samples older than (pos - one frame) are no longer needed by any kernel; while a step is in flight
     // sh.st.pos is still the position before it, so the region its kernels read is protected as well
     if (sh.wr + n - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
-    uint8_t *ring = c->d_ring + static_cast<size_t>(s) * len * c->bps;
+    uint8_t *ring = c->ring_of(s);
     const hipMemcpyKind mk = kind == DABX_SRC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     hipStream_t q = kind == DABX_SRC_PINNED ? c->copy_stream : c->stream;
     int64_t done = 0;
     while (done < n) {
         const int64_t w = (sh.wr + done) % len, chunk = std::min(n - done, len - w);
-        HIPCHK(hipMemcpyAsync(ring + w * c->bps, static_cast<const uint8_t *>(src) + done * c->bps,
-                              static_cast<size_t>(chunk) * c->bps, mk, q));
+        const uint8_t *from = static_cast<const uint8_t *>(src) + done * c->bps;
+        HIPCHK(hipMemcpyAsync(ring + w * c->bps, from, static_cast<size_t>(chunk) * c->bps, mk, q));
+        if (w < DABX_RING_MIRROR)                    // the head of the ring is mirrored behind its end
+            HIPCHK(hipMemcpyAsync(ring + (len + w) * c->bps, from, static_cast<size_t>(std::min<int64_t>(chunk, DABX_RING_MIRROR - w)) * c->bps, mk, q));
         done += chunk;
     }
     if (kind == DABX_SRC_HOST) HIPCHK(hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
@@ -465,9 +472,11 @@ int dabx_push_all(dabx_ctx *c, const void *src, size_t stride, int64_t n, int ki
             int64_t done = 0;
             while (done < n) {                       // at most two pieces: the ring wraps at the same place in every stream
                 const int64_t w = (c->streams[0].wr + done) % len, chunk = std::min(n - done, len - w);
-                HIPCHK(hipMemcpy2DAsync(c->d_ring + w * c->bps, static_cast<size_t>(len) * c->bps,
-                                        static_cast<const uint8_t *>(src) + done * c->bps, stride,
-                                        static_cast<size_t>(chunk) * c->bps, S, mk, q));
+                const uint8_t *from = static_cast<const uint8_t *>(src) + done * c->bps;
+                HIPCHK(hipMemcpy2DAsync(c->d_ring + w * c->bps, c->stride(), from, stride, static_cast<size_t>(chunk) * c->bps, S, mk, q));
+                if (w < DABX_RING_MIRROR)
+                    HIPCHK(hipMemcpy2DAsync(c->d_ring + (len + w) * c->bps, c->stride(), from, stride,
+                                            static_cast<size_t>(std::min<int64_t>(chunk, DABX_RING_MIRROR - w)) * c->bps, S, mk, q));
                 done += chunk;
             }
             if (kind == DABX_SRC_HOST) HIPCHK(hipStreamSynchronize(c->stream));
@@ -506,7 +515,7 @@ int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int 
     if ((rc = grow(c->d_rs_in, c->rs_in_cap, static_cast<size_t>(n) * bpc))) return rc;
     HIPCHK(hipMemcpyAsync(c->d_rs_in, src, static_cast<size_t>(n) * bpc, hipMemcpyHostToDevice, q));
     rs::State *st = c->d_rs_state + s;
-    short2 *ring = reinterpret_cast<short2 *>(c->d_ring + static_cast<size_t>(s) * len * c->bps);
+    short2 *ring = reinterpret_cast<short2 *>(c->ring_of(s));
     int64_t n_out = 0;
     // the reference picks the converter by rate (inputdevicesrc.cpp:33-47)
     if (copy || ds2) {
@@ -570,7 +579,7 @@ int dabx_read_ring(dabx_ctx *c, int s, int64_t from, int64_t n, void *dst)
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->cfg.device);
     const int64_t len = c->cfg.ring_samples;
-    const uint8_t *ring = c->d_ring + static_cast<size_t>(s) * len * c->bps;
+    const uint8_t *ring = c->ring_of(s);
     HIPCHK(hipStreamSynchronize(c->stream));
     int64_t done = 0;
     while (done < n) {
@@ -595,7 +604,7 @@ void dabx_free_pinned(void *p)
 void *dabx_ring_ptr(dabx_ctx *c, int s)
 {
     if (!valid_stream(c, s)) return nullptr;
-    return c->d_ring + static_cast<size_t>(s) * c->cfg.ring_samples * c->bps;
+    return c->ring_of(s);
 }
 
 int dabx_set_write_pos(dabx_ctx *c, int s, int64_t wr)

@@ -193,8 +193,22 @@ __device__ __forceinline__ int64_t wrap(int64_t n, int64_t len)
     return w < 0 ? w + len : w;
 }
 
-// 2048-sample window starting at ring index `widx` (already wrapped), de-rotated
-// by -inc with phase zero `phase_off` samples before the window
+// one complex sample as floats: u8 pairs are offset binary (value - 128), s16 pairs signed; both conversions are exact
+template <int FMT>
+__device__ __forceinline__ cf sample_f(const uint8_t *ring, uint32_t idx)
+{
+    if (FMT == 0) {
+        const uint32_t u = reinterpret_cast<const uint16_t *>(ring)[idx];
+        return {(float)(u & 0xffu) - 128.0f, (float)(u >> 8) - 128.0f};          // v_cvt_f32_ubyte0 / ubyte1 + one subtraction
+    }
+    const uint32_t u = reinterpret_cast<const uint32_t *>(ring)[idx];
+    return {(float)(int16_t)(u & 0xffff), (float)(int16_t)(u >> 16)};
+}
+
+// 2048-sample window starting at ring index `widx` (already wrapped, wave-uniform), de-rotated
+// by -inc with phase zero `phase_off` samples before the window.  The head of the ring is mirrored behind its end
+// (DABX_RING_MIRROR samples, kept by the host side), so the window never wraps: the eight loads of a thread are a
+// scalar base + 2 t + an immediate — no per-sample address arithmetic.
 template <int FMT>
 __device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const uint8_t *ring, int64_t ring_len,
                                             int64_t widx, uint32_t phase_off, int32_t inc, int t)
@@ -202,14 +216,14 @@ __device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const u
     const uint32_t dth = (uint32_t)(-(int64_t)inc);
     const cf step = nco(T, dth * 256u);
     cf rot = nco(T, dth * (phase_off + (uint32_t)t));
+    const uint8_t *base = ring + widx * (FMT == 0 ? 2 : 4);                      // uniform: scalar registers
+    cf x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = sample_f<FMT>(base, (uint32_t)(t + 256 * j));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        int64_t idx = widx + t + 256 * j;
-        if (idx >= ring_len) idx -= ring_len;
-        int si, sq;
-        sample<FMT>(ring, idx, si, sq);
         if (j) rot = cmul(rot, step);
-        v[j] = cmul({(float)si, (float)sq}, rot);
+        v[j] = cmul(x[j], rot);
     }
 }
 

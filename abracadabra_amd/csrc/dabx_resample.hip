@@ -50,6 +50,15 @@ __device__ __forceinline__ short2 to_s16(float2 y, float gain)
     return make_short2((short)a, (short)b);
 }
 
+// sample `pos` (absolute) of a stream: into the ring and, for the head of the ring, into its mirror behind the end
+constexpr int RING_MIRROR = 4096;            // = DABX_RING_MIRROR (include/dabx.h)
+__device__ __forceinline__ void ring_store(short2 *ring, int64_t ring_len, int64_t pos, short2 v)
+{
+    const int64_t w = pos % ring_len;
+    ring[w] = v;
+    if (w < RING_MIRROR) ring[ring_len + w] = v;
+}
+
 // one output per thread: y[n] = sum_c coef[c] (x[2n-42+2c] + x[2n-2c]) + 0.5 x[2n-21]
 template <int FMT>
 __global__ __launch_bounds__(256) void k_resample_ds2(const void *in, int n_out, const State *st, short2 *ring, int64_t ring_len, int64_t wr,
@@ -85,9 +94,7 @@ __global__ __launch_bounds__(256) void k_resample_ds2(const void *in, int n_out,
         u = m.y * ds2_coef[11];
         accQ = accQ + u;
     }
-    int64_t w = wr + n;
-    w = w % ring_len;
-    ring[w] = to_s16(make_float2(accI, accQ), gain);
+    ring_store(ring, ring_len, wr + n, to_s16(make_float2(accI, accQ), gain));
 }
 
 // after the block: the history for the next call = the last 42 input samples (n_in even, >= 0)
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256) void k_resample_copy(const void *in, int n, sh
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    ring[(wr + k) % ring_len] = to_s16(in_sample<FMT>(in, k), gain);
+    ring_store(ring, ring_len, wr + k, to_s16(in_sample<FMT>(in, k), gain));
 }
 
 // Transposed Farrow, pass 1: one thread per segment (the input samples integrated between two dumps).
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256) void k_farrow_outputs(const float2 *A, int n_d
             const float2 a = s >= 0 ? A[(size_t)s * FW_N + i] : st->fw_a[FW_N - 1 + s][i];
             yI = yI + a.x; yQ = yQ + a.y;
         }
-        ring[(wr + j) % ring_len] = to_s16(make_float2(R * yI, R * yQ), gain);
+        ring_store(ring, ring_len, wr + j, to_s16(make_float2(R * yI, R * yQ), gain));
     }
 }
 

@@ -137,7 +137,10 @@ DABX_API void *dabx_alloc_pinned(size_t bytes);
 DABX_API void  dabx_free_pinned(void *p);
 
 /* Device address of a stream's ring and a way to declare samples resident
- * without copying (zero-copy producers, and the benchmark's periodic signal). */
+ * without copying (zero-copy producers, and the benchmark's periodic signal).  The ring is followed by a mirror of its
+ * first DABX_RING_MIRROR samples (so that no FFT window wraps): dabx_push and dabx_push_resampled maintain it; a producer
+ * that writes through this pointer writes sample i < DABX_RING_MIRROR of the ring also at index ring_samples + i. */
+#define DABX_RING_MIRROR 4096
 DABX_API void *dabx_ring_ptr(dabx_ctx *ctx, int stream);
 DABX_API int   dabx_set_write_pos(dabx_ctx *ctx, int stream, int64_t wr);
 
