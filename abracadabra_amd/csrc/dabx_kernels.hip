@@ -162,11 +162,37 @@ __device__ __forceinline__ void fft2048(cf v[8], float2 *buf, int t, const Twidd
     fft2048_core(v, buf, t, tw.a, tw.b, tw.c, nullptr);
 }
 
+// x + x[lane ^ d] for d = 1, 2, 4, 8, 16, 32 in that order (the xor butterfly of the arithmetic contract) without a trip
+// through the LDS crossbar: DPP for 1, 2, 4, 8; for 16 and 32 gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// the odd rows (upper half) of one copy with the even rows (lower half) of another, after which copy A + copy B is
+// x + x[lane ^ 16] (x + x[lane ^ 32]) in every lane.
+__device__ __forceinline__ float wave_xor_sum(float x)
+{
+#define DABX_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    x = x + DABX_DPP(x, 0xB1);                                   // quad_perm [1,0,3,2]
+    x = x + DABX_DPP(x, 0x4E);                                   // quad_perm [2,3,0,1]
+    {                                                            // lane ^ 4: banks 0, 2 read lane + 4, banks 1, 3 read lane - 4
+        int o = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0x5, false);          // row_shl:4
+        o = __builtin_amdgcn_update_dpp(o, __float_as_int(x), 0x114, 0xf, 0xa, false);              // row_shr:4
+        x = x + __int_as_float(o);
+    }
+    x = x + DABX_DPP(x, 0x128);                                  // row_ror:8
+#undef DABX_DPP
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return x;
+}
+
 // fixed-order block sum (256 threads): xor butterfly in each wave, then (W0+W1)+(W2+W3)
 __device__ __forceinline__ float reduce256(float x, float *red /*4 floats*/, int t)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) x = x + __shfl_xor(x, d, 64);
+    x = wave_xor_sum(x);
     __syncthreads();
     if ((t & 63) == 0) red[t >> 6] = x;
     __syncthreads();
@@ -548,7 +574,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     const DevTables &T = C.tab;
     __shared__ __attribute__((aligned(16))) float2 buf[FFT_LDS];
     __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) int8_t soft[SYMBITS];
+    __shared__ __attribute__((aligned(16))) uint16_t soft[NCAR + 64];   // one (Re, Im) soft-bit pair per carrier + a dummy slot per lane
     const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
     int8_t *fic = C.fic_soft + ((size_t)s * C.max_frames + f) * FICBITS;
     int8_t *ti = C.ti + (size_t)s * C.ti_slots * CIFBITS;
@@ -557,15 +583,17 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     __shared__ float2 twl[TWL];
     cf twa[7];
     load_twiddles_lds(twa, twl, T.W, t);
-    // where the soft bits of each FFT output position go in the staging buffer (-1: unused bin): the frequency
-    // de-interleaver index n itself for FIC symbols ([0]), its residue-major place (n & 15) * 192 + (n >> 4) for MSC
-    // symbols ([1]); the imaginary part sits 1536 resp. 96 bytes further (1536 = 16 * 96)
+    // where the soft-bit pair of each FFT output position goes in the staging buffer: the frequency de-interleaver index n
+    // itself for FIC symbols ([0]), its residue-major place (n & 15) * 96 + (n >> 4) for MSC symbols ([1]); the bins
+    // outside the 1536 carriers go to a dummy slot of the lane (no branch around the store), used[] masks them out of the sum
     __shared__ int16_t dst_l[2][TU];
+    uint32_t used = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int n = T.n_of_bin[T.bin_of_pos[8 * t + e]];
-        dst_l[0][8 * t + e] = static_cast<int16_t>(n);
-        dst_l[1][8 * t + e] = static_cast<int16_t>(n < 0 ? -1 : (n & 15) * (SYMBITS / 16) + (n >> 4));
+        used |= (n >= 0 ? 1u : 0u) << e;
+        dst_l[0][8 * t + e] = static_cast<int16_t>(n < 0 ? NCAR + (t & 63) : n);
+        dst_l[1][8 * t + e] = static_cast<int16_t>(n < 0 ? NCAR + (t & 63) : (n & 15) * (NCAR / 16) + (n >> 4));
     }
 
     const int l_first = g * DEMOD_GSYMS;                 // first symbol to demap (0 = PRS: reference only)
@@ -583,35 +611,49 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             int nidx[8];
             float acc = 0.0f;
             const int16_t *tab = dst_l[l <= 3 ? 0 : 1];
-            const int imoff = l <= 3 ? NCAR : NCAR / 16;
 #pragma unroll
             for (int e = 0; e < 8; ++e) nidx[e] = tab[8 * t + e];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 y[e] = cmulc(v[e], prev[e]);
-                if (nidx[e] >= 0) { float a = fabsf(y[e].r) + fabsf(y[e].i); acc = acc + a; }
+                const float a = fabsf(y[e].r) + fabsf(y[e].i);
+                acc = acc + ((used >> e) & 1u ? a : 0.0f);               // adding +0 leaves the sum as it is
             }
             float S = reduce256(acc, red, t), gsc = 0.0f;
             if (S > 0.0f && S < __builtin_inff()) { int E; frexpf(S, &E); gsc = ldexpf(1.0f, SOFT_EXP - E); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (nidx[e] >= 0) {
-                    float a = rintf(y[e].r * gsc), b = rintf(y[e].i * gsc);
-                    a = __builtin_amdgcn_fmed3f(a, -SOFT_MAX, SOFT_MAX); b = __builtin_amdgcn_fmed3f(b, -SOFT_MAX, SOFT_MAX);   // clamp in one instruction
-                    soft[nidx[e]] = (int8_t)a;
-                    soft[nidx[e] + imoff] = (int8_t)b;
-                }
+            for (int e = 0; e < 8; ++e) {
+                // rint(y * gsc) clamped to +-63: gsc is a power of two, so the product is exact and adding 1.5 * 2^23 rounds it
+                // to the nearest integer (ties to even) into the low bits of the float — the same value as rintf(), one FMA
+                const int a = __float_as_int(__builtin_fmaf(y[e].r, gsc, 12582912.0f)) - 0x4B400000;
+                const int b = __float_as_int(__builtin_fmaf(y[e].i, gsc, 12582912.0f)) - 0x4B400000;
+                const int qa = min(max(a, -(int)SOFT_MAX), (int)SOFT_MAX), qb = min(max(b, -(int)SOFT_MAX), (int)SOFT_MAX);
+                soft[nidx[e]] = (uint16_t)((qa & 0xff) | ((qb & 0xff) << 8));
+            }
             __syncthreads();
-            if (l <= 3) {
-                int8_t *dst = fic + (l - 1) * SYMBITS;
-                if (t < SYMBITS / 16) reinterpret_cast<int4 *>(dst)[t] = reinterpret_cast<const int4 *>(soft)[t];
-            } else if (t < SYMBITS / 16) {
-                // residue-major row: bit b of the CIF lives at (b & 15) * TI_SEG + (b >> 4); `soft`
-                // was filled in that order (see below), 16 segments of 192 bytes per symbol
-                int8_t *row = ti + (size_t)((cif0 + (l - 4) / 18) & (C.ti_slots - 1)) * CIFBITS;
-                const int res = t / 12, part = t % 12;
-                reinterpret_cast<int4 *>(row + res * TI_SEG + ((l - 4) % 18) * (SYMBITS / 16))[part] =
-                    reinterpret_cast<const int4 *>(soft + res * (SYMBITS / 16))[part];
+            if (t < NCAR / 16) {
+                // 16 carriers per thread: 32 bytes of pairs -> 16 Re bytes and 16 Im bytes
+                const uint4 p0 = reinterpret_cast<const uint4 *>(soft)[2 * t], p1 = reinterpret_cast<const uint4 *>(soft)[2 * t + 1];
+                uint4 re, im;
+                re.x = __builtin_amdgcn_perm(p0.y, p0.x, 0x06040200); im.x = __builtin_amdgcn_perm(p0.y, p0.x, 0x07050301);
+                re.y = __builtin_amdgcn_perm(p0.w, p0.z, 0x06040200); im.y = __builtin_amdgcn_perm(p0.w, p0.z, 0x07050301);
+                re.z = __builtin_amdgcn_perm(p1.y, p1.x, 0x06040200); im.z = __builtin_amdgcn_perm(p1.y, p1.x, 0x07050301);
+                re.w = __builtin_amdgcn_perm(p1.w, p1.z, 0x06040200); im.w = __builtin_amdgcn_perm(p1.w, p1.z, 0x07050301);
+                int8_t *dst;
+                int imoff;
+                if (l <= 3) {                                            // FIC: bit n = Re of carrier n, bit n + 1536 = Im
+                    dst = fic + (l - 1) * SYMBITS + 16 * t;
+                    imoff = NCAR;
+                } else {
+                    // residue-major row: bit b of the CIF lives at (b & 15) * TI_SEG + (b >> 4): 16 segments of 192 bytes
+                    // per symbol, each Re (96 bytes) then Im (96 bytes); the staging buffer is in that order
+                    int8_t *row = ti + (size_t)((cif0 + (l - 4) / 18) & (C.ti_slots - 1)) * CIFBITS;
+                    const int res = t / 6, part = t % 6;
+                    dst = row + res * TI_SEG + ((l - 4) % 18) * (SYMBITS / 16) + 16 * part;
+                    imoff = NCAR / 16;
+                }
+                *reinterpret_cast<uint4 *>(dst) = re;
+                *reinterpret_cast<uint4 *>(dst + imoff) = im;
             }
         }
 #pragma unroll
