@@ -846,7 +846,8 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging buffer in LDS: [keep, send][64 dwords], then the 16 dwords of the address table
+//   xs:     the wave's soft-value staging buffer in LDS: keep rows at dword 0, send rows at dword 80 (64 each), the 16
+//           dwords of the address table at 144
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
@@ -877,17 +878,18 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 48..63 fetch nothing
     // A row of this lane: rows 0, 1 = keep of steps ph, ph + 6; rows 2, 3 = send of the same steps (LDS byte address:
     // the low 32 bits of a shared pointer)
-    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 1) + 256u * ((lane >> 1) & 1);
-    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 128;
+    // the send plane starts 80 dwords in: the four addresses of a read (rows 0..3) then fall into four different LDS banks
+    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 1) + 320u * ((lane >> 1) & 1);
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 144;
     const int sh = src.slot_mask < 0 ? 4 : 0;
-    if (lane < 16) xs[128 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
+    if (lane < 16) xs[144 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
     int xk, xs_;
     gather_step(src, tab, sh, step_word(info, tl, nsteps), xk, xs_);
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
         xs[lane] = xk;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
-        xs[64 + lane] = xs_;                                     // operations execute in order, the previous block's reads are done
+        xs[80 + lane] = xs_;                                     // operations execute in order, the previous block's reads are done
         gather_step(src, tab, sh, wnext, xk, xs_);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
         const uint32_t va = va0;
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][144];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][160];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     int *xs = xs_all[wave];
     uint32_t *ring = ring_all[wave];
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][144];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][160];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);

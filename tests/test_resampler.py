@@ -129,3 +129,36 @@ def test_gpu_decodes_an_ensemble_recorded_at_another_rate(gpu_ctx_factory, rate,
         assert gok.all() and np.array_equal(gf, fib[done:done + 2])
         done += 2
     assert ctx.state(0)["locked"] == 1
+
+
+@pytest.mark.gpu
+def test_gpu_resampled_stream_through_a_small_ring(gpu_ctx_factory):
+    """4.096 Msps input streamed through a ring of four frames: the ring wraps three times, the windows that start near
+    its end read the mirrored head the resampler kernel maintains (DABX_RING_MIRROR)"""
+    sub = ob.subch_layout(2, 64)
+    nf = 13
+    iq, fib, _ = ob.tx_generate(seed=34, n_frames=nf, subch=sub, delay=900, fmt=1, snr_db=25.0, cfo_hz=-700.0, rms=2000.0)
+    x = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    xr = signal.resample_poly(x, 2, 1)
+    dev = np.clip(np.rint(np.stack([xr.real, xr.imag], axis=1).reshape(-1)), -32768, 32767).astype(np.int16)
+    ctx = gpu_ctx_factory(n_streams=1, fmt=1, ring_frames=4, max_frames=1)
+    ctx.set_subchannels(0, sub)
+    orc = ob.Resampler(4096e3)
+    o = ob.Stream(fmt=1, subch=sub, ring_len=4 * ob.TF)
+    pos, done = 0, 0
+    chunk = 2 * 2 * 98304                                         # half a frame of output per push
+    while pos < dev.size:
+        part = dev[pos:pos + chunk]
+        pos += chunk
+        n = ctx.push_resampled(0, part, 4096e3)
+        o.push(ob.to_s16(orc.process(part.astype(np.float32))))
+        assert n == part.size // 4
+        while ctx.frames_available() >= 1:
+            ctx.process(1)
+            r = o.process(1)
+            gf, gok = ctx.fib(0)
+            assert np.array_equal(ctx.sync(0), r["sync"]) and np.array_equal(ctx.fic_soft(0), r["fic_soft"])
+            assert np.array_equal(gf, r["fib"]) and np.array_equal(gok, r["fib_ok"])
+            assert gok.all() and np.array_equal(gf[0], fib[done])
+            done += 1
+    assert done >= nf - 2
