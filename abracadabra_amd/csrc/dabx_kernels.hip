@@ -706,35 +706,40 @@ struct VitSrc {
 // classes of a codeword start at 16 fixed places.  Time de-interleaved: class k lives in row (r + bitrev4(k)) of the
 // ring, at k * TI_SEG inside it (sub-channels start on 64-bit boundaries, so base already points at start_bit >> 4),
 // consecutive members one byte apart (sh = 0).  Linear (FIC, stage tests): tab[k] = k, members 16 bytes apart (sh = 4).
-// The wave keeps the table in LDS: an address costs and / shift / read / shift-add instead of nine instructions.
+// Entries 16..18 continue the table for bits i+1..i+3 of a step that starts in class 13..15: tab[k - 16] + (1 << sh).
+// The wave keeps the table in LDS: the four addresses of a step cost one and / shift-add, four reads with immediate
+// offsets and four adds.
 __device__ __forceinline__ uint32_t soft_tab_entry(const VitSrc &src, uint32_t k)
 {
-    if (src.slot_mask < 0) return k;
+    const uint32_t wrap = k >> 4;
+    k &= 15u;
+    if (src.slot_mask < 0) return k + (wrap << 4);
     const uint32_t d = __builtin_bitreverse32(k) >> 28;            // delay of residue class k: bit-reversed k
     // the offset stays below 2^32 (at most 64 rows of 55296 bytes): 24-bit multiplies
-    return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(k, (uint32_t)TI_SEG);
+    return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(k, (uint32_t)TI_SEG) + wrap;
 }
 
-// depuncturing word of trellis step tau (0 = past the end: nothing to fetch)
+// depuncturing word of trellis step tau (0 = past the end)
 __device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info, int tau, int nsteps)
 {
     return tau < nsteps ? info[tau] : 0u;
 }
 // The soft values of the step described by w as the two A rows the matrix core wants: keep = (x0 + x3, x1, x2, 1),
-// send = (-(x0 + x3), -x1, -x2, 0), one byte each, zero where punctured.  x0 and x3 belong to the same generator
-// polynomial and |x| <= 63, so their sum fits a byte.  The four loads are unconditional (a punctured position re-reads
-// the next kept bit, a valid address) and issued together, so no branch and no wait sits between them.
+// send = (x0 + x3, x1, x2, 0), one byte each, zero where punctured.  x0 and x3 belong to the same generator polynomial
+// and |x| <= 63, so their sum fits a byte.  A step keeps a prefix of its four bits (dabx_spec.hpp: step_info), so the
+// four bytes at the step's offset are loaded unconditionally (issued together, no branch, valid addresses: the buffers
+// carry slack) and the punctured ones are masked off.
 __device__ __forceinline__ void gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w, int &keep, int &send)
 {
-    const uint32_t k0 = (w >> 3) & 1u, k1 = (w >> 2) & 1u, k2 = (w >> 1) & 1u, k3 = w & 1u;
-    const uint32_t i0 = w >> 4, i1 = i0 + k0, i2 = i1 + k1, i3 = i2 + k2;
-    const int8_t *base = src.base;
-    const uint32_t a0 = tab[i0 & 15u] + ((i0 >> 4) << sh), a1 = tab[i1 & 15u] + ((i1 >> 4) << sh);
-    const uint32_t a2 = tab[i2 & 15u] + ((i2 >> 4) << sh), a3 = tab[i3 & 15u] + ((i3 >> 4) << sh);
-    const int b0 = base[a0], b1 = base[a1], b2 = base[a2], b3 = base[a3];
-    const int x03 = (b0 & (0 - (int)k0)) + (b3 & (0 - (int)k3)), x1 = b1 & (0 - (int)k1), x2 = b2 & (0 - (int)k2);
-    keep = (x03 & 0xff) | ((x1 & 0xff) << 8) | ((x2 & 0xff) << 16) | (1 << 24);
-    send = ((0 - x03) & 0xff) | (((0 - x1) & 0xff) << 8) | (((0 - x2) & 0xff) << 16);
+    const uint32_t i0 = w >> 5;
+    const uint32_t *t = tab + (i0 & 15u);
+    const uint32_t q = (i0 >> 4) << sh;
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(src.base);
+    const uint32_t b0 = base[t[0] + q], b1 = base[t[1] + q], b2 = base[t[2] + q], b3 = base[t[3] + q];
+    const uint32_t W = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) & (0xFFFFFFFFu >> (w & 31u));
+    const uint32_t x03 = (W + (W >> 24)) & 0xFFu;                  // byte arithmetic modulo 256: two's complement sum
+    send = (int)(x03 | (W & 0x00FFFF00u));
+    keep = send | (1 << 24);
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
@@ -747,7 +752,7 @@ __device__ __forceinline__ void gather_step(const VitSrc &src, const uint32_t *t
 // over those six steps; they are shifted into the lane's decision word (v_alignbit) and cleared.  A metric tie keeps
 // the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag bits are still zero.
 // Range: |metric| <= 27654 steps x 4 x 63 x 64 < 2^31.
-// Both 64 M + tag and -64 M come from the matrix core: six v_mfma_i32_4x4x4_16b_i8 per 12 steps (one per phase, see
+// Both 64 M + tag and 64 M come from the matrix core: six v_mfma_i32_4x4x4_16b_i8 per 12 steps (one per phase, see
 // tools/gen_acs32.py), otherwise idle, while the vector ALU is what bounds this kernel.  Their A operands are the
 // packed soft values of the chunk, staged in LDS memory by the lanes that gathered them (keep rows and send rows):
 // lane l reads row l mod 4.
@@ -846,7 +851,7 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging buffer in LDS: keep rows at dword 0, send rows at dword 80 (64 each), the 16
+//   xs:     the wave's soft-value staging buffer in LDS: keep rows at dword 0, send rows at dword 80 (64 each), the 19
 //           dwords of the address table at 144
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
@@ -882,7 +887,7 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 1) + 320u * ((lane >> 1) & 1);
     const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 144;
     const int sh = src.slot_mask < 0 ? 4 : 0;
-    if (lane < 16) xs[144 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
+    if (lane < 19) xs[144 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
     int xk, xs_;
     gather_step(src, tab, sh, step_word(info, tl, nsteps), xk, xs_);
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][160];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][164];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     int *xs = xs_all[wave];
     uint32_t *ring = ring_all[wave];
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][160];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][164];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);

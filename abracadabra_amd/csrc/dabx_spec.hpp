@@ -205,14 +205,17 @@ inline bool any_profile(int option, int level, int kbps, Profile &p)
     return option == 2 ? uep_profile(level, p) : eep_profile(option, level, kbps, p);
 }
 
-// depuncturing map: per trellis step, (offset of first kept bit << 4) | keep mask (bit 3 = x0)
+// depuncturing map: per trellis step, (offset of its first kept bit << 5) | 8 * (4 - number of kept bits).  Every
+// puncturing vector of EN 300 401 table 29 keeps a PREFIX of the four mother-code bits of a step (1000, 1100, 1110 or
+// 1111), so the kept soft bits are the next `ones` bits of the stream and the low field is the right shift that turns
+// 0xFFFFFFFF into their byte mask.
 inline std::vector<uint32_t> step_info(const Profile &p)
 {
     std::vector<uint32_t> info;
     info.reserve(p.steps());
     uint32_t off = 0;
     auto emit = [&](int ones) {
-        info.push_back((off << 4) | (0xFu & ~(0xFu >> ones)));
+        info.push_back((off << 5) | static_cast<uint32_t>(8 * (4 - ones)));
         off += ones;
     };
     for (int s = 0; s < p.nseg; ++s)

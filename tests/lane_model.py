@@ -48,7 +48,7 @@ def decode(x4):
     travel with the path through the max.  Both candidates come straight from the matrix core: with the soft values
     packed as (x0 + x3, x1, x2, 1) — generators 0 and 3 of the DAB mother code are the same polynomial, and the sum
     fits a byte because |x| <= 63 — and the lane's signs as (+-64, +-64, +-64, 1 << ph), the keep row gives
-    64 M + tag and the row with the negated soft values and a 0 in the last column gives -64 M.  At the end of a
+    64 M + tag and the row with a 0 in the last column gives 64 M, which is subtracted.  At the end of a
     group of six steps the six tags go into the lane's decision word (four groups = 24 steps per word) and are
     cleared.  A tie keeps the own path: the kept candidate has its tag bit set, the received one does not, all
     higher tag bits are zero.  The traceback walks six steps per look-up: position ^= ~tags."""
@@ -71,11 +71,11 @@ def decode(x4):
                 t = (4 * w + gi) * 6 + ph
                 x = x4[t].astype(np.int64)
                 a_keep = np.array([x[0] + x[3], x[1], x[2], 1])        # MFMA A rows (int8 each)
-                a_send = np.array([-(x[0] + x[3]), -x[1], -x[2], 0])
+                a_send = np.array([x[0] + x[3], x[1], x[2], 0])
                 assert np.abs(a_keep).max() <= 127
                 b = np.concatenate([64 * sig[ph][:, :3], np.full((64, 1), 1 << ph)], axis=1)   # MFMA B column of every lane
                 keep = pm + b @ a_keep
-                send = pm + b @ a_send
+                send = pm - b @ a_send
                 recv = send[lanes ^ XV[ph]]
                 pm = np.maximum(keep, recv)
                 assert np.abs(pm).max() < 2 ** 31
