@@ -913,7 +913,7 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
-        if (pend >= VIT_UNIT + 4 && !(pend & 1)) {               // 96, 144, 192 steps after the unit's end
+        if (pend >= VIT_UNIT + 2 && !(pend & 1)) {               // 48, 96, 144, 192 steps after the unit's end
             const int B = w_ring + VIT_UNIT;
             uint32_t O;
             if (survivors_merged(ring, w_hi, B, coordA, O)) {
