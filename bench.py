@@ -306,13 +306,18 @@ def run_rank(args, engine_factory=None):
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
         torch.cuda.set_device(dev)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (tests): a process group and the collectives also for a single rank, so that the RCCL path
+    # (init with device_id, barrier, all_reduce on device tensors) runs on a one-GPU box
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        import torch
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.backend)
-    red_device = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
+    red_device = "cuda" if ((world > 1 or force_dist) and args.backend == "nccl") else "cpu"
 
     from oracle import binding as ob             # signal synthesis + the cpu_baseline leg only
     sub = ob.subch_layout(args.nsub, 64)         # default: all 864 CU = 18 x 48 CU, EEP 3-A, 64 kbit/s
@@ -332,7 +337,7 @@ def run_rank(args, engine_factory=None):
         engine.load(s, iq)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         if gpu:
             torch.cuda.synchronize()
@@ -366,7 +371,7 @@ def run_rank(args, engine_factory=None):
         engine.close()
         pcie = pcie_leg(args, dev, streams, sub)
 
-    elapsed, (ok, bad, mism, checked, n_streams) = reduce_over_ranks(dist, world, red_device, elapsed, [ok, bad, mism, checked, S])
+    elapsed, (ok, bad, mism, checked, n_streams) = reduce_over_ranks(dist, 2 if force_dist else world, red_device, elapsed, [ok, bad, mism, checked, S])
 
     rc = 0
     if rank == 0:
@@ -388,6 +393,7 @@ def run_rank(args, engine_factory=None):
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 FFT / int8 soft bits / int32 path metrics", "data": "synthetic",
+            "collective": (dist.get_backend() if dist is not None else None),
             "config": {"workload": f"configs[3]: {S} concurrent synthetic Mode-I ensembles per GPU, full FIC + MSC ({args.nsub} x 48 CU EEP 3-A) Viterbi",
                        "streams_per_gpu": S, "frames_per_step": F, "snr_db": args.snr, "sample_format": "u8 IQ 2.048 Msps",
                        "parallelism": f"{world} x independent streams, no data-path collective"},
@@ -423,7 +429,7 @@ def run_rank(args, engine_factory=None):
             print(f"bench.py: FAILED correctness: fib_crc_bad={bad} payload_mismatch={mism}", file=sys.stderr)
             rc = 1
     engine.close()
-    if world > 1:
+    if dist is not None:
         # every rank leaves with the same verdict
         import torch as _t
         v = _t.tensor([float(rc)], dtype=_t.float64, device=red_device)

@@ -87,6 +87,22 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["config"]["streams_per_gpu"] == 8 and d["scaling"] == "weak"
 
 
+def test_bench_collectives_run_over_rccl_on_this_gpu():
+    """one rank, but with the process group and the collectives of the N > 1 path (BENCH_FORCE_DIST): init_process_group("nccl",
+    device_id), barrier and all_reduce of device tensors execute over RCCL on the test box's GPU"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_FORCE_DIST="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--streams", "8", "--steps", "2", "--warmup", "3",
+                          "--no-cpu-baseline", "--no-pcie"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["collective"] == "nccl" and d["n_gpus"] == 1 and d["fib_crc_bad"] == 0 and d["fib_crc_ok"] == 8 * 8 * 12
+
+
 def test_bench_line_contract_single_gpu():
     d = _bench(["--streams", "16", "--steps", "3", "--warmup", "3", "--cpu-seconds", "1", "--cpu-threads", "2", "--no-pcie"])
     assert d["n_gpus"] == 1 and d["fib_crc_bad"] == 0 and d["payload_mismatch"] == 0
