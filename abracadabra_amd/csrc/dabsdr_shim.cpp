@@ -88,6 +88,7 @@ struct dabsdr_s {
     int gain_shift = 0;                  // float -> s16 scaling: x * 2^gain_shift
     bool gain_set = false;
     std::vector<float> first_frame;      // input held back until one whole frame has been seen (the gain is fixed on it)
+    int16_t *frame_s16 = nullptr;        // the frame being collected for the GPU: page-locked, so its copy needs no synchronisation
     float frame_peak = 0.0f;             // |sample| peak of the frame in progress (gain hysteresis)
     int frame_fill = 0;
     int msc_stride = 0;                  // bytes per CIF of the running selections, as the GPU context has them
@@ -498,13 +499,22 @@ int choose_shift(const float *in, size_t n_values)
 
 void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
 {
+    // plain float arithmetic the compiler vectorises: x * g is exact (power of two), adding and subtracting 1.5 * 2^23
+    // rounds to the nearest integer, ties to even (|x * g| < 2^22 after the clamp), like std::nearbyint but without a call
     const float g = std::ldexp(1.0f, h->gain_shift);
-    float peak = h->frame_peak;
-    for (int i = 0; i < n_values; ++i) {
-        float v = std::nearbyint(in[i] * g);
-        peak = std::fmax(peak, std::fabs(v));
-        out[i] = static_cast<int16_t>(v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v));
-    }
+    float pk[16];                                                       // sixteen independent running maxima: no serial dependency
+    for (int j = 0; j < 16; ++j) pk[j] = h->frame_peak;
+    for (int i = 0; i + 16 <= n_values; i += 16)                        // n_values is a multiple of 16 (chunks of 16384 samples)
+        for (int j = 0; j < 16; ++j) {
+            float v = in[i + j] * g;
+            v = v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v);
+            v = (v + 12582912.0f) - 12582912.0f;
+            const float a = v < 0.0f ? -v : v;
+            pk[j] = a > pk[j] ? a : pk[j];
+            out[i + j] = static_cast<int16_t>(static_cast<int32_t>(v));
+        }
+    float peak = pk[0];
+    for (int j = 1; j < 16; ++j) peak = pk[j] > peak ? pk[j] : peak;
     h->frame_peak = peak;
     h->frame_fill += n_values / 2;
     if (h->frame_fill >= DABX_FRAME_SAMPLES) {                          // once per frame: hysteresis
@@ -776,10 +786,14 @@ void worker_loop(dabsdr_s *h)
     while (!h->exit_req.load()) {
         if (!serve(h->frequency == 0)) return;
         if (h->frequency == 0 || !h->ctx || !h->input) continue;
-        // one transmission frame of input, then decode whatever is complete
-        for (int got = 0; got < DABX_FRAME_SAMPLES && !h->exit_req.load(); got += kPullChunk) {
-            if (got && !serve(false)) return;
-            if (h->frequency == 0 || !h->ctx) break;
+        // one transmission frame of input — converted chunk by chunk into one host buffer and handed to the GPU in a single
+        // copy (a copy per 8 ms chunk cost twelve synchronisations per frame) — then decode whatever is complete
+        if (!h->frame_s16) h->frame_s16 = static_cast<int16_t *>(dabx_alloc_pinned(2 * static_cast<size_t>(DABX_FRAME_SAMPLES) * sizeof(int16_t)));
+        if (!h->frame_s16) return;
+        bool complete = true;
+        for (int got = 0; got < DABX_FRAME_SAMPLES; got += kPullChunk) {
+            if (h->exit_req.load() || (got && !serve(false))) { if (!h->exit_req.load()) return; complete = false; break; }
+            if (h->frequency == 0 || !h->ctx) { complete = false; break; }
             h->input(h->fbuf.data(), static_cast<uint16_t>(kPullChunk));
             if (!h->gain_set) {                                         // the first frame after a tune fixes the gain
                 h->first_frame.insert(h->first_frame.end(), h->fbuf.begin(), h->fbuf.end());
@@ -787,22 +801,23 @@ void worker_loop(dabsdr_s *h)
                 h->gain_shift = choose_shift(h->first_frame.data(), h->first_frame.size());
                 h->gain_set = true;
                 h->frame_fill = 0; h->frame_peak = 0.0f;
-                bool ok = true;
-                for (size_t o = 0; ok && o < h->first_frame.size(); o += 2 * kPullChunk) {
-                    convert(h, h->first_frame.data() + o, h->sbuf.data(), 2 * kPullChunk);
-                    ok = dabx_push(h->ctx, 0, h->sbuf.data(), kPullChunk, 0) == DABX_OK;
-                }
+                for (size_t o = 0; o < h->first_frame.size(); o += 2 * kPullChunk)
+                    convert(h, h->first_frame.data() + o, h->frame_s16 + o, 2 * kPullChunk);
                 h->first_frame.clear(); h->first_frame.shrink_to_fit();
-                if (!ok) break;
-                continue;
+                (void)dabx_push(h->ctx, 0, h->frame_s16, DABX_FRAME_SAMPLES, DABX_SRC_PINNED);
+                complete = false;                                       // this frame has gone; start collecting the next one
+                break;
             }
-            convert(h, h->fbuf.data(), h->sbuf.data(), 2 * kPullChunk);
-            if (dabx_push(h->ctx, 0, h->sbuf.data(), kPullChunk, 0) != DABX_OK) break;
+            convert(h, h->fbuf.data(), h->frame_s16 + 2 * static_cast<size_t>(got), 2 * kPullChunk);
         }
+        if (complete && h->gain_set && h->first_frame.empty() && dabx_push(h->ctx, 0, h->frame_s16, DABX_FRAME_SAMPLES, DABX_SRC_PINNED) != DABX_OK) continue;
+        bool stepped = false;
         while (!h->exit_req.load() && dabx_frames_available(h->ctx) >= 1) {
-            if (dabx_process(h->ctx, 1) != DABX_OK) break;
+            if (dabx_process(h->ctx, 1) != DABX_OK) break;       // waits for the queued copy of the frame buffer
+            stepped = true;
             after_step(h);
         }
+        if (!stepped && h->ctx) dabx_flush_copies(h->ctx);       // the frame buffer is refilled next: its copy must have left it
     }
 }
 
@@ -866,6 +881,7 @@ void dabsdrDeinit(dabsdrHandle_t *handle)
         h->worker.join();
     }
     if (h->ctx) dabx_destroy(h->ctx);
+    if (h->frame_s16) dabx_free_pinned(h->frame_s16);
     delete h;
     *handle = nullptr;
 }

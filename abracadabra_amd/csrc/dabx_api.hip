@@ -88,6 +88,11 @@ struct dabx_ctx {
     int32_t *d_cordic = nullptr;
     float *d_spectrum = nullptr, *d_null_spectrum = nullptr;   // optional, dabx_enable_spectrum
     DevState *h_state = nullptr;            // pinned mirror
+    // single-stream contexts (the legacy 24-function path: one ensemble, one frame per step) get their small per-step
+    // results with the step itself, into page-locked memory: the getters then cost no HIP call (each synchronous
+    // device-to-host copy of a few hundred bytes took ~22 us, eight of them per 96 ms frame)
+    uint8_t *h_res = nullptr;               // [F][384] fib | [F][12] fib_ok | [F][64] sync | [2][2048] float spectra
+    bool res_valid = false;
 
     std::vector<StreamHost> streams;
     std::vector<uint32_t> info_pool;        // depuncturing maps, FIC first
@@ -368,6 +373,7 @@ static int create_body(dabx_ctx *c, const dabx_config_t *cfg)
     ALLOC(c->d_sub, S * 64 * sizeof(DevSub));
 #undef ALLOC
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_state), S * sizeof(DevState)));
+    if (S == 1) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_res), F * (384 + 12 + sizeof(DevSync)) + 2 * 2048 * sizeof(float)));
     std::memset(c->h_state, 0, S * sizeof(DevState));
     c->h_sub.assign(S * 64, DevSub{});
     int rc = upload_tables(c);
@@ -389,6 +395,7 @@ void dabx_destroy(dabx_ctx *c)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -590,6 +597,15 @@ int dabx_read_ring(dabx_ctx *c, int s, int64_t from, int64_t n, void *dst)
     return DABX_OK;
 }
 
+int dabx_flush_copies(dabx_ctx *c)
+{
+    if (!c) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    return DABX_OK;
+}
+
 void *dabx_alloc_pinned(size_t bytes)
 {
     void *p = nullptr;
@@ -676,6 +692,18 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     if (c->timing) HIPCHK(hipEventRecord(c->ev[4], q));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_state, c->d_state, static_cast<size_t>(S) * sizeof(DevState), hipMemcpyDeviceToHost, q));
+    c->res_valid = false;
+    if (c->h_res) {
+        const size_t F = c->cfg.max_frames, n = n_frames;
+        uint8_t *p = c->h_res;
+        HIPCHK(hipMemcpyAsync(p, c->d_fib, n * 384, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipMemcpyAsync(p + F * 384, c->d_fib_ok, n * 12, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipMemcpyAsync(p + F * 396, c->d_sync, n * sizeof(DevSync), hipMemcpyDeviceToHost, q));
+        float *sp = reinterpret_cast<float *>(p + F * (396 + sizeof(DevSync)));
+        if (c->d_spectrum) HIPCHK(hipMemcpyAsync(sp, c->d_spectrum, 2048 * sizeof(float), hipMemcpyDeviceToHost, q));
+        if (c->d_null_spectrum) HIPCHK(hipMemcpyAsync(sp + 2048, c->d_null_spectrum, 2048 * sizeof(float), hipMemcpyDeviceToHost, q));
+        c->res_valid = true;
+    }
     c->pending = true;
     c->last_frames = n_frames;
     return DABX_OK;
@@ -717,6 +745,11 @@ int dabx_process(dabx_ctx *c, int n_frames)
 int dabx_get_fib(dabx_ctx *c, int s, uint8_t *fib, uint8_t *ok)
 {
     GETTER_PROLOGUE
+    if (c->res_valid) {
+        if (fib) std::memcpy(fib, c->h_res, n * 384);
+        if (ok) std::memcpy(ok, c->h_res + F * 384, n * 12);
+        return DABX_OK;
+    }
     if (fib) HIPCHK(hipMemcpy(fib, c->d_fib + s * F * 384, n * 384, hipMemcpyDeviceToHost));
     if (ok) HIPCHK(hipMemcpy(ok, c->d_fib_ok + s * F * 12, n * 12, hipMemcpyDeviceToHost));
     return DABX_OK;
@@ -737,6 +770,7 @@ int dabx_get_sync(dabx_ctx *c, int s, dabx_sync_rec_t *rec)
     GETTER_PROLOGUE
     static_assert(sizeof(dabx_sync_rec_t) == sizeof(DevSync), "sync record layout");
     if (!rec) return DABX_E_ARG;
+    if (c->res_valid) { std::memcpy(rec, c->h_res + F * 396, n * sizeof(DevSync)); return DABX_OK; }
     HIPCHK(hipMemcpy(rec, c->d_sync + s * F, n * sizeof(DevSync), hipMemcpyDeviceToHost));
     return DABX_OK;
 }
@@ -843,6 +877,7 @@ int dabx_enable_spectrum(dabx_ctx *c, int mask)
     (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
     const size_t bytes = static_cast<size_t>(c->cfg.n_streams) * 2048 * sizeof(float);
+    c->res_valid = false;                            // the result mirror of the last step does not hold what is enabled now
     float **bufs[2] = {&c->d_spectrum, &c->d_null_spectrum};
     for (int k = 0; k < 2; ++k) {
         const bool want = (mask >> k) & 1;
@@ -861,6 +896,7 @@ int dabx_get_spectrum(dabx_ctx *c, int s, float *power)
 {
     GETTER_PROLOGUE
     if (!power || !c->d_spectrum) return DABX_E_ARG;
+    if (c->res_valid) { std::memcpy(power, c->h_res + F * (396 + sizeof(DevSync)), 2048 * sizeof(float)); return DABX_OK; }
     HIPCHK(hipMemcpy(power, c->d_spectrum + static_cast<size_t>(s) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
     return DABX_OK;
 }
@@ -869,6 +905,7 @@ int dabx_get_null_spectrum(dabx_ctx *c, int s, float *power)
 {
     GETTER_PROLOGUE
     if (!power || !c->d_null_spectrum) return DABX_E_ARG;
+    if (c->res_valid) { std::memcpy(power, c->h_res + F * (396 + sizeof(DevSync)) + 2048 * sizeof(float), 2048 * sizeof(float)); return DABX_OK; }
     HIPCHK(hipMemcpy(power, c->d_null_spectrum + static_cast<size_t>(s) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
     return DABX_OK;
 }

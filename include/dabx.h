@@ -131,6 +131,10 @@ DABX_API int64_t dabx_push_resampled(dabx_ctx *ctx, int stream, const void *src,
 /* Test/diagnostic accessor: copies n complex samples starting at absolute sample index `from` out of a stream's ring. */
 DABX_API int dabx_read_ring(dabx_ctx *ctx, int stream, int64_t from, int64_t n, void *dst);
 
+/* Wait until every DABX_SRC_PINNED copy queued so far has left its source buffer (for a producer that wants to refill the
+ * buffer without a decode step in between). */
+DABX_API int dabx_flush_copies(dabx_ctx *ctx);
+
 /* Page-locked host buffers for DABX_SRC_PINNED (a file reader fills them directly, as RawFileWorker
  * fills its read buffer: reference src/input/rawfileinput.cpp:640-713). */
 DABX_API void *dabx_alloc_pinned(size_t bytes);
