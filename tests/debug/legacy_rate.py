@@ -8,6 +8,8 @@ from legacy_host import NID, LegacyHost
 sub = [[0, 0, 3, 64]]
 P = 12
 iq, _, _ = ob.tx_generate(seed=5, eid=0x1234, n_frames=P, subch=sub, loop=1, snr_db=25.0)
+if len(sys.argv) > 1:                      # write the periodic signal for the C host (legacy_rate.c) and stop
+    iq.tofile(sys.argv[1]); sys.exit(0)
 N = 50                                     # periods
 sig = np.tile(iq.astype(np.float32) - 128.0, N)
 host = LegacyHost(sig)
