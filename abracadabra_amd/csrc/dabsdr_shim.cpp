@@ -714,7 +714,12 @@ void after_step(dabsdr_s *h)
                 for (int c = 0; c < 4; ++c) {
                     if (!valid[c]) continue;
                     const uint8_t *frame = msc.data() + static_cast<size_t>(c) * stride + off;
-                    if (sp->packet) { sp->pkt.feed_frame(frame, static_cast<int>(fb)); continue; }
+                    if (sp->packet) {
+                        auto fe = h->db.fec_scheme.find(sp->subch_id);          // FIG 0/14 may arrive after the selection
+                        sp->pkt.set_fec(fe != h->db.fec_scheme.end() && fe->second == 1);
+                        sp->pkt.feed_frame(frame, static_cast<int>(fb));
+                        continue;
+                    }
                     dabsdrAudioCBData_t d;
                     d.id = sp->id; d.ASCTy = static_cast<uint8_t>(sp->ascty); d.header.raw = 0;
                     d.auLen = static_cast<uint16_t>(fb); d.pAuData = frame;
@@ -975,10 +980,12 @@ DABSDR_API int dabsdr_amd_pad_decode_mp2(const uint8_t *frames, int n_bytes, uin
 
 // test hook (CPU only): logical frames of a packet-mode sub-channel (n_frames x frame_bytes) -> data groups as records
 // {addr lo, addr hi, len lo, len hi, bytes}; address < 0 follows every address; stats[4] = packets, CRC errors, groups, dropped
-DABSDR_API int dabsdr_amd_packet_decode(const uint8_t *frames, int n_frames, int frame_bytes, int address, uint8_t *out, int cap, uint32_t *stats)
+// dabsdr_amd_packet_decode_fec: the same for a sub-channel with FEC frames (FIG 0/14 scheme 1); stats[7] adds FEC frames, corrected bytes, failed rows
+static int packet_decode(const uint8_t *frames, int n_frames, int frame_bytes, int address, bool fec, uint8_t *out, int cap, uint32_t *stats, int n_stats)
 {
     packet::Decoder dec;
     dec.address = address;
+    dec.set_fec(fec);
     int used = 0;
     bool overflow = false;
     dec.on_data_group = [&](int addr, const uint8_t *d, int n) {
@@ -989,8 +996,20 @@ DABSDR_API int dabsdr_amd_packet_decode(const uint8_t *frames, int n_frames, int
         used += 4 + n;
     };
     for (int i = 0; i < n_frames; ++i) dec.feed_frame(frames + static_cast<size_t>(i) * frame_bytes, frame_bytes);
-    if (stats) { stats[0] = dec.stats.packets; stats[1] = dec.stats.crc_err; stats[2] = dec.stats.groups; stats[3] = dec.stats.dropped; }
+    dec.set_fec(false);                                   // hands on what an unfinished table holds
+    const uint32_t all[7] = {dec.stats.packets, dec.stats.crc_err, dec.stats.groups, dec.stats.dropped, dec.stats.fec_frames, dec.stats.fec_corrected, dec.stats.fec_failed_rows};
+    if (stats) std::memcpy(stats, all, sizeof(uint32_t) * static_cast<size_t>(n_stats));
     return overflow ? -1 : used;
+}
+
+DABSDR_API int dabsdr_amd_packet_decode(const uint8_t *frames, int n_frames, int frame_bytes, int address, uint8_t *out, int cap, uint32_t *stats)
+{
+    return packet_decode(frames, n_frames, frame_bytes, address, false, out, cap, stats, 4);
+}
+
+DABSDR_API int dabsdr_amd_packet_decode_fec(const uint8_t *frames, int n_frames, int frame_bytes, int address, uint8_t *out, int cap, uint32_t *stats)
+{
+    return packet_decode(frames, n_frames, frame_bytes, address, true, out, cap, stats, 7);
 }
 
 // test hook (CPU only): parse FIBs and print the ensemble as text, see tests/test_figdb.py

@@ -70,12 +70,23 @@ class LegacyHost:
                     it = CompItem()
                     cl.getItem(self.handle, i, C.byref(it))
                     comps.append(dict(scids=it.SCIdS, subch=it.SubChId, addr=it.SubChAddr, size=it.SubChSize, prot=it.protectionLevel, ps=it.ps,
-                                      tmid=it.TMId, ascty=it.u.streamAudio.ASCTy, kbps=it.u.streamAudio.bitRate))
+                                      tmid=it.TMId, ascty=it.u.streamAudio.ASCTy, kbps=it.u.streamAudio.bitRate, fec=it.uepIdx))   # uepIdx / fecScheme: one union
                 rec.update(sid=cl.SId, comps=comps)
             with self.lock:
                 self.events.append(rec)
 
-        self._keep = (get_samples, on_ntf)
+        class DgCB(C.Structure):                      # dabsdrDataGroupCBData_t (dabsdr.h:89-96)
+            _fields_ = [("id", C.c_int), ("SCId", C.c_uint16), ("userAppType", C.c_uint16), ("dgLen", C.c_uint16), ("pDgData", C.POINTER(C.c_uint8))]
+
+        self.data_groups = []
+
+        @C.CFUNCTYPE(None, C.POINTER(DgCB), C.c_void_p)
+        def on_dg(p, ctx):
+            d = p.contents
+            with self.lock:
+                self.data_groups.append((d.id, d.SCId, d.userAppType, bytes(np.ctypeslib.as_array(d.pDgData, shape=(d.dgLen,)))))
+
+        self._keep = (get_samples, on_ntf, on_dg)
         L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
         assert L.dabsdrInit(C.byref(self.handle)) == 0
         for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
@@ -83,6 +94,8 @@ class LegacyHost:
             getattr(L, name)(self.handle, C.cast(get_samples, C.c_void_p))
         L.dabsdrRegisterNotificationCb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabsdrRegisterNotificationCb(self.handle, C.cast(on_ntf, C.c_void_p), None)
+        L.dabsdrRegisterDataGroupCb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabsdrRegisterDataGroupCb(self.handle, C.cast(on_dg, C.c_void_p), None)
         for name in ("dabsdr", "dabsdrRequest_GetEnsemble", "dabsdrRequest_GetServiceList", "dabsdrRequest_Exit"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.dabsdrRequest_Tune.argtypes = [C.c_void_p, C.c_uint32]

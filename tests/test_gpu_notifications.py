@@ -91,6 +91,54 @@ def test_user_application_update_xpad_start_and_refused_reconfiguration():
         host.close()
 
 
+def test_packet_mode_fec_frames_are_corrected_once_fig_0_14_announces_them():
+    """FIG 0/14 (FEC sub-channel organisation): the packet sub-channel carries RS(204,188) FEC frames (EN 300 401 §5.3.5); byte
+    errors planted in the sub-channel's bytes BEFORE channel coding (so the Viterbi decoder hands them on) are corrected by the
+    outer code, every data group arrives, and the component list reports fecScheme = 1 (dabsdr.h:202-206)."""
+    from legacy_host import NID, LegacyHost
+    from tests.test_packet_mode import fec_stream, to_frames
+    sub = [[0, 0, 3, 64], [48, 0, 3, 32]]
+    sid, n_frames = 0x1A01, 36
+    rng = np.random.default_rng(12)
+    groups = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(30, 120, 60)]
+    stream = bytearray(fec_stream(groups, 0x155, per_frame=12))       # 5 FEC frames of 2472 bytes; 96 bytes per logical frame
+    n_fec = len(stream) // 2472
+    assert n_fec == 5
+    for f in range(2, n_fec):                                         # the selection starts inside frame 1, whose FEC packets lock the decoder
+        for r in range(12):
+            for c in rng.choice(188, size=int(rng.integers(2, 9)), replace=False):
+                stream[f * 2472 + int(c) * 12 + r] ^= int(rng.integers(1, 256))
+    prows = to_frames(stream, 96)[:n_frames * 4]
+    assert len(prows) * 96 >= n_fec * 2472
+    payload = np.zeros((n_frames * 4, 192 + 96), dtype=np.uint8)
+    payload[:, :192] = rng.integers(0, 256, (n_frames * 4, 192), dtype=np.uint8)
+    payload[:len(prows), 192:] = prows
+    iq, _, _ = ob.tx_generate(seed=97, eid=0x1236, n_frames=n_frames, subch=sub, delay=2500, snr_db=22.0, cfo_hz=300.0, payload=payload, packet_sub=1)
+    host = LegacyHost(iq.astype(np.float32) - 128.0, gate_at=8 * 196608)
+    L = host.L
+    try:
+        host.tune()
+        host.wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)
+        time.sleep(0.5)
+        _inject(host, [fib(fig0(14, [(1 << 2) | 1]))])                # SubChId 1, FEC scheme 1
+        L.dabsdrRequest_GetServiceComponents(host.handle, sid)
+        comps = host.wait_for(lambda e: e["nid"] == NID["SERVICE_COMPONENT_LIST"] and e["status"] == 0)[-1]["comps"]
+        pk = [c for c in comps if c["tmid"] == 3]
+        assert len(pk) == 1 and pk[0]["subch"] == 1 and pk[0]["fec"] == 1
+        L.dabsdrRequest_ServiceSelection(host.handle, sid, 1, -1)     # SCIdS 1: the packet component, data decoder
+        assert host.wait_for(lambda e: e["nid"] == NID_SERVICE_SELECTION)[-1]["status"] == 0
+        host.open_gate()
+        host.wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e["at"] >= (n_frames + 1) * 196608, timeout=60)
+        with host.lock:
+            got = [g[3] for g in host.data_groups]
+        # frames before the selection (8 + the interleaver's 15 CIFs) are gone; from the first complete FEC frame on nothing is missing
+        first = groups.index(got[0])
+        assert got == groups[first:first + len(got)]
+        assert len(got) >= 36 and groups[-1] in got                   # the last three FEC frames, error-laden, complete
+    finally:
+        host.close()
+
+
 def test_deinit_while_the_input_callback_blocks():
     """the host's getSamples waits on a condition variable until samples arrive (inputdevice.cpp:70-85); Deinit must not
     hang on it (the reference cancels its thread)"""
