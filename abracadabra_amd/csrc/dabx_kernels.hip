@@ -839,7 +839,11 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
     }
     P &= 63u;
     O = (uint32_t)__builtin_amdgcn_readfirstlane((int)P);
+#ifdef DABX_PROBE_FORCE_MERGE
+    return (__builtin_amdgcn_ballot_w64(P != O) | 1) != 0;          // timing probes whose decisions are wrong: always "merged"
+#else
     return __builtin_amdgcn_ballot_w64(P != O) == 0;
+#endif
 }
 
 // Decode one terminated codeword with the calling wave.  Every DAB codeword has 192 k + 6 steps: n_in is a multiple
@@ -895,8 +899,10 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     for (int blk = 0; blk <= nblk; ++blk) {
         xs[lane] = xk;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
         xs[80 + lane] = xs_;                                     // operations execute in order, the previous block's reads are done
+#ifndef DABX_PROBE_NOGATHER
         gather_step(src, tab, sh, wnext, xk, xs_);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
+#endif
         const uint32_t va = va0;
         uint32_t bits = 0;
         if (blk == nblk) {                                       // the six tail steps: no output, from state 0 (lane 0)
@@ -913,7 +919,11 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
+#ifdef DABX_PROBE_NOTRACE
+        if (false) {
+#else
         if (pend >= VIT_UNIT + 2 && !(pend & 1)) {               // 48, 96, 144, 192 steps after the unit's end
+#endif
             const int B = w_ring + VIT_UNIT;
             uint32_t O;
             if (survivors_merged(ring, w_hi, B, coordA, O)) {
@@ -926,7 +936,9 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
             }
         }
     }
+#ifndef DABX_PROBE_NOTRACE
     trace_words(ring, dec, w_ring, w_dec, 2 * nblk, A, out32, prbs32, lane);
+#endif
 }
 
 }  // namespace
