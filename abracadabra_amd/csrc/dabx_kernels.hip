@@ -245,7 +245,12 @@ __device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const u
     const uint8_t *base = ring + widx * (FMT == 0 ? 2 : 4);                      // uniform: scalar registers
     cf x[8];
 #pragma unroll
+#ifdef DABX_PROBE_NOLOAD
+    for (int j = 0; j < 8; ++j) x[j] = {(float)((t + 7 * j) & 31) - 16.0f, (float)((t * 3 + j) & 31) - 16.0f};   // timing probe: no memory
+    (void)base;
+#else
     for (int j = 0; j < 8; ++j) x[j] = sample_f<FMT>(base, (uint32_t)(t + 256 * j));
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (j) rot = cmul(rot, step);
