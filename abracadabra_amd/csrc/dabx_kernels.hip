@@ -117,6 +117,7 @@ __device__ __forceinline__ void load_twiddles_lds(cf a[7], float2 *twl, const fl
 // The caller must __syncthreads() before the next use of buf.
 // twa/twb/twc: the thread's twiddles of the three radix-8 passes (registers), or, when twl is given,
 // passes B and C read theirs from the LDS table of load_twiddles_lds().
+template <bool SYNC = true>
 __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const cf *twa, const cf *twb, const cf *twc, const float2 *twl)
 {
     r8(v);
@@ -124,7 +125,7 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
     for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], twa[c - 1]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(t + 256 * c)] = make_float2(v[c].r, v[c].i);
-    __syncthreads();
+    if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
     int base = (t >> 5) * 256 + (t & 31);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 32 * j)]; v[j] = {x.x, x.y}; }
@@ -136,7 +137,7 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 32 * c)] = make_float2(v[c].r, v[c].i);
-    __syncthreads();
+    if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
     base = (t >> 2) * 32 + (t & 3);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 4 * j)]; v[j] = {x.x, x.y}; }
@@ -148,7 +149,7 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].r, v[c].i);
-    __syncthreads();
+    if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
     {   // positions 8t .. 8t+7 are contiguous (never across a pad): four 16-byte reads, conflict-free per 8 lanes
         const float4 *p = reinterpret_cast<const float4 *>(buf + pad(8 * t));
 #pragma unroll
@@ -610,7 +611,11 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
         load_window<FMT>(v, T, ring, C.ring_len, widx, (uint32_t)(l * TS), rec.inc, t);
         widx += TS;
         if (widx >= C.ring_len) widx -= C.ring_len;
+#ifdef DABX_PROBE_DEMOD_NOBARRIER
+        fft2048_core<false>(v, buf, t, twa, nullptr, nullptr, twl);
+#else
         fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
+#endif
         if (l > l_ref) {
             cf y[8];
             int nidx[8];
