@@ -679,8 +679,17 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     if (u8) hipLaunchKernelGGL(k_sync<0>, dim3(S * n_frames), dim3(256), 0, q, d, n_frames);
     else hipLaunchKernelGGL(k_sync<1>, dim3(S * n_frames), dim3(256), 0, q, d, n_frames);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], q));
-    if (u8) hipLaunchKernelGGL(k_demod<0>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
-    else hipLaunchKernelGGL(k_demod<1>, dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+    // the variant for streams whose sampling clock is off is launched only if the state the last step left says one exists
+    // (the host mirror is what the kernels will read: only k_finish and the calls that write both change it)
+    bool any_sco = false;
+    for (const auto &sh : c->streams) any_sco |= sh.st.locked && (sh.st.slope >= SCO_MIN || sh.st.slope <= -SCO_MIN);
+    if (u8) {
+        hipLaunchKernelGGL((k_demod<0, false>), dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+        if (any_sco) hipLaunchKernelGGL((k_demod<0, true>), dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+    } else {
+        hipLaunchKernelGGL((k_demod<1, false>), dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+        if (any_sco) hipLaunchKernelGGL((k_demod<1, true>), dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
+    }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
     if (c->n_work) hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
     if (c->timing) HIPCHK(hipEventRecord(c->ev[5], q));

@@ -31,6 +31,7 @@ constexpr int EARLY_SPAN = 400;            // the first path may lead the strong
 constexpr float EARLY_THR = 0.125f;        // ... if it carries at least this fraction of its power (-9 dB)
 constexpr int RESYNC_THR = 32;             // PRS further than this from where the window expected it: second pass
 constexpr int SLOPE_MAX = 60 << 16;        // sampling-clock tracker: |drift| <= 60 samples per frame (~300 ppm), Q16
+constexpr int SCO_MIN = 1 << 16;           // de-rotate the differential product from this drift on: 1 sample per frame = 5.1 ppm
 constexpr int TI_SEG = CIFBITS / 16;   // bytes per residue class in a residue-major MSC row
 
 struct cf { float r, i; };
@@ -568,7 +569,10 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
 // spectrum stays in registers (same thread owns the same bins in every symbol).
 constexpr int DEMOD_GROUPS = 4, DEMOD_GSYMS = 19;          // (2 x 38 and 1 x 76 symbols per workgroup run at the same speed)
 
-template <int FMT>
+// SCO: the variant that de-rotates the differential product for streams whose sampling clock is off (below).  Both
+// variants are launched over the whole grid; a workgroup whose stream belongs to the other one leaves at once.  (One
+// kernel holding both symbol loops costs the common loop a spilled twiddle and 6 % of its time.)
+template <int FMT, bool SCO>
 __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 {
     const int g = blockIdx.x % DEMOD_GROUPS;
@@ -602,6 +606,28 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
         dst_l[1][8 * t + e] = static_cast<int16_t>(n < 0 ? NCAR + (t & 63) : (n & 15) * (NCAR / 16) + (n >> 4));
     }
 
+    // Sampling-clock offset: the windows keep their nominal spacing, so a recording whose clock is off by eps sees every
+    // symbol eps * TS samples later in its window than the one before: a phase of -2 pi k eps TS / TU on carrier k in the
+    // differential product (34 degrees at the band edge for 100 ppm).  From SCO_MIN on it is turned back with the tracked
+    // drift: dth = slope * 319 / 768 is that phase per carrier in 2^-32 turns; the carrier of FFT output 8 t + e is
+    // b0(t) + m(e), so the factor is rt (per thread) times sm[e] (uniform: scalar registers).
+    const int32_t slope = (rec.flags & 2) ? 0 : st.slope;        // an acquisition step starts without a drift estimate
+    const bool sco = slope >= SCO_MIN || slope <= -SCO_MIN;      // workgroup-uniform
+    if (sco != SCO) return;
+    __shared__ float2 rt_l[SCO ? 256 : 1];                       // the threads' factors: kept in LDS, the registers are all taken
+    cf sm[8];
+    if (SCO) {
+        const int32_t dth = (int32_t)(((int64_t)slope * 319) / 768);
+        const int m_e[8] = {0, 512, -1024, -512, 64, 576, -960, -448};
+        const cf rt = nco(T, (uint32_t)(((t >> 5) + 8 * ((t >> 2) & 7) + 128 * (t & 3)) * dth));
+        rt_l[t] = make_float2(rt.r, rt.i);                       // read back by the same thread only
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const cf x = nco(T, (uint32_t)(m_e[e] * dth));
+            sm[e] = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x.r))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x.i)))};
+        }
+    }
+
     const int l_first = g * DEMOD_GSYMS;                 // first symbol to demap (0 = PRS: reference only)
     const int l_ref = l_first == 0 ? 0 : l_first - 1;    // symbol whose spectrum seeds the differential
     const int l_last = l_first + DEMOD_GSYMS - 1;
@@ -626,6 +652,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 y[e] = cmulc(v[e], prev[e]);
+                if constexpr (SCO) { const float2 r = rt_l[t]; y[e] = cmul(cmul(y[e], sm[e]), {r.x, r.y}); }
                 const float a = fabsf(y[e].r) + fabsf(y[e].i);
                 acc = acc + ((used >> e) & 1u ? a : 0.0f);               // adding +0 leaves the sum as it is
             }
@@ -1072,5 +1099,7 @@ template __global__ void k_null_search<0>(DevCtx);
 template __global__ void k_null_search<1>(DevCtx);
 template __global__ void k_sync<0>(DevCtx, int);
 template __global__ void k_sync<1>(DevCtx, int);
-template __global__ void k_demod<0>(DevCtx, int);
-template __global__ void k_demod<1>(DevCtx, int);
+template __global__ void k_demod<0, false>(DevCtx, int);
+template __global__ void k_demod<1, false>(DevCtx, int);
+template __global__ void k_demod<0, true>(DevCtx, int);
+template __global__ void k_demod<1, true>(DevCtx, int);

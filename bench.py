@@ -197,9 +197,10 @@ def profile_counters(S, F, kernel="k_viterbi"):
         except Exception:
             continue
         if t.get("workload") == {"streams": S, "frames_per_step": F}:
-            for k, v in t["kernels"].items():
-                if kernel in k:
-                    return v.get("hbm_bytes_per_launch"), v.get("insts_valu_per_launch"), os.path.basename(f)
+            hits = [v for k, v in t["kernels"].items() if kernel in k]      # k_demod has two variants: the one that did the work
+            if hits:
+                v = max(hits, key=lambda x: x.get("hbm_bytes_per_launch") or 0)
+                return v.get("hbm_bytes_per_launch"), v.get("insts_valu_per_launch"), os.path.basename(f)
     return None, None, None
 
 

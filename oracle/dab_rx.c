@@ -32,6 +32,7 @@
 #define EARLY_SPAN 400      /* the first path may lead the strongest one by up to this many samples ...   */
 #define EARLY_THR 0.125f    /* ... if it carries at least this fraction of its power (-9 dB)               */
 #define SLOPE_MAX (60 << 16)/* sampling-clock tracker: |drift| <= 60 samples per frame (~300 ppm), Q16      */
+#define SCO_MIN (1 << 16)            /* de-rotate the differential product from this drift on: 1 sample per frame = 5.1 ppm */
 
 /* ------------------------------------------------------------------ tables */
 typedef struct {
@@ -504,9 +505,23 @@ static void sync_pass(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx
 
 /* demodulate the 76 symbols of one frame: FIC soft bits to fic[9216], MSC soft
  * bits into the time de-interleaver ring slots (cif0 + c) & 15 */
-static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *fic)
+static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *fic, int32_t slope)
 {
     float pr[NFFT], pi[NFFT], xr[NFFT], xi[NFFT], yr[NFFT], yi[NFFT], part[256];
+    /* Sampling-clock offset: with the windows at their nominal spacing a recording whose clock is off by eps sees every
+     * symbol eps * TS samples later in its window than the one before, i.e. a phase of -2 pi k eps TS / TU on carrier k
+     * in the differential product (34 degrees at the band edge for 100 ppm).  From SCO_MIN (about 5 ppm) on the product
+     * is turned back with the tracked drift: dth = slope * 319 / 768 is that phase per carrier in 2^-32 turns
+     * (2^32 * TS / (TU * 65536 * TF) = 319 / 768), the factor of position 8 t + e is R[t] * S[e], carrier
+     * = b0(t) + m(e) as the FFT leaves its bins (tables_init). */
+    static const int m_e[8] = {0, 512, -1024, -512, 64, 576, -960, -448};
+    const int comp = slope >= SCO_MIN || slope <= -SCO_MIN;
+    const int32_t dth = (int32_t)(((int64_t)slope * 319) / 768);
+    float rtr[256], rti[256], smr[8], smi[8];
+    if (comp) {
+        for (int t = 0; t < 256; t++) nco((uint32_t)(((t >> 5) + 8 * ((t >> 2) & 7) + 128 * (t & 3)) * dth), &rtr[t], &rti[t]);
+        for (int e = 0; e < 8; e++) nco((uint32_t)(m_e[e] * dth), &smr[e], &smi[e]);
+    }
     /* The symbol windows of a frame keep their nominal spacing: moving a window by a whole sample between two symbols
      * would put a phase step of 2 pi k / 2048 into the differential product.  A sampling-clock error of 100 ppm moves
      * the last symbol by 20 samples against the first, which the BACKOFF of the window inside the guard absorbs. */
@@ -520,6 +535,10 @@ static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *f
                     int p = 8 * t + e;
                     if (T.n_of_bin[T.bin_of_pos[p]] < 0) continue;
                     cmulc(xr[p], xi[p], pr[p], pi[p], &yr[p], &yi[p]);
+                    if (comp) {
+                        cmul(yr[p], yi[p], smr[e], smi[e], &yr[p], &yi[p]);
+                        cmul(yr[p], yi[p], rtr[t], rti[t], &yr[p], &yi[p]);
+                    }
                     float a = fabsf(yr[p]) + fabsf(yi[p]);
                     acc = acc + a;
                 }
@@ -709,7 +728,7 @@ int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8
         sync_frame(s, pos_f, s->inc, wide, &rec, f == n_frames - 1 ? s->spectrum : NULL, f == n_frames - 1 ? s->null_spectrum : NULL);
         if (sync) sync[f] = rec;
         int64_t cif0 = s->cif + 4 * (int64_t)f;
-        demod_frame(s, &rec, cif0, ficbuf);
+        demod_frame(s, &rec, cif0, ficbuf, s->slope);
         if (fic_soft) memcpy(fic_soft + (size_t)f * DAB_FIC_BITS, ficbuf, DAB_FIC_BITS);
         if (msc_soft)
             for (int c = 0; c < 4; c++)

@@ -142,6 +142,6 @@ def test_gpu_lock_time_frequency_offset_and_input_scale(cfo, scale):
         assert [s["sid"] for s in sl["services"]] == [0x1A01] and sl["services"][0]["pty"] == (255, 255)
         host.L.dabsdrRequest_GetServiceComponents(host.handle, 0x1A01)
         cl = host.wait_for(lambda e: e["nid"] == NID["SERVICE_COMPONENT_LIST"] and e.get("sid") == 0x1A01)[-1]
-        assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, prot=8, ps=2, tmid=0, ascty=63, kbps=64)]
+        assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, prot=8, ps=2, tmid=0, ascty=63, kbps=64, fec=0)]
     finally:
         host.close()
