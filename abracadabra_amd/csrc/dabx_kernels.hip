@@ -24,8 +24,8 @@ namespace {
 constexpr int TF = 196608, TNULL = 2656, TS = 2552, TU = 2048, TG = 504;
 constexpr int NSYM = 76, SYMBITS = 3072, NCAR = 1536;
 constexpr int FICBITS = 9216, CIFBITS = 55296;
-constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 16, PM_INIT = -1000000;
-constexpr float SOFT_MAX = 63.0f;          // soft bits are limited to +-63: the sum of two fits a byte (k_viterbi packs x0 + x3)
+constexpr int BACKOFF = 24, CFO_RANGE = 16, SOFT_EXP = 15, PM_INIT = -1000000;
+constexpr float SOFT_MAX = 31.0f;          // soft bits are limited to +-31: twice the sum of two fits a byte (k_viterbi packs 2 (x0 + x3))
 constexpr float LOCK_THR = 48.0f;
 constexpr int EARLY_SPAN = 400;            // the first path may lead the strongest one by up to this many samples ...
 constexpr float EARLY_THR = 0.125f;        // ... if it carries at least this fraction of its power (-9 dB)
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             if (S > 0.0f && S < __builtin_inff()) { int E; frexpf(S, &E); gsc = ldexpf(1.0f, SOFT_EXP - E); }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                // rint(y * gsc) clamped to +-63: gsc is a power of two, so the product is exact and adding 1.5 * 2^23 rounds it
+                // rint(y * gsc) clamped to +-31: gsc is a power of two, so the product is exact and adding 1.5 * 2^23 rounds it
                 // to the nearest integer (ties to even) into the low bits of the float — the same value as rintf(), one FMA
                 const int a = __float_as_int(__builtin_fmaf(y[e].r, gsc, 12582912.0f)) - 0x4B400000;
                 const int b = __float_as_int(__builtin_fmaf(y[e].i, gsc, 12582912.0f)) - 0x4B400000;
@@ -761,12 +761,12 @@ __device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info,
 {
     return tau < nsteps ? info[tau] : 0u;
 }
-// The soft values of the step described by w as the two A rows the matrix core wants: keep = (x0 + x3, x1, x2, 1),
-// send = (x0 + x3, x1, x2, 0), one byte each, zero where punctured.  x0 and x3 belong to the same generator polynomial
-// and |x| <= 63, so their sum fits a byte.  A step keeps a prefix of its four bits (dabx_spec.hpp: step_info), so the
-// four bytes at the step's offset are loaded unconditionally (issued together, no branch, valid addresses: the buffers
-// carry slack) and the punctured ones are masked off.
-__device__ __forceinline__ void gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w, int &keep, int &send)
+// The soft values of the step described by w as the A row the matrix core wants: (2 (x0 + x3), 2 x1, 2 x2, tag), one byte
+// each, zero where punctured.  x0 and x3 belong to the same generator polynomial and |x| <= 31, so twice their sum fits a
+// byte.  A step keeps a prefix of its four bits (dabx_spec.hpp: step_info), so the four bytes at the step's offset are
+// loaded unconditionally (issued together, no branch, valid addresses: the buffers carry slack) and the punctured ones
+// are masked off.  tag = (1 << phase of the step) << 24, a constant of the lane that gathers it.
+__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w, uint32_t tag)
 {
     const uint32_t i0 = w >> 5;
     const uint32_t *t = tab + (i0 & 15u);
@@ -775,38 +775,41 @@ __device__ __forceinline__ void gather_step(const VitSrc &src, const uint32_t *t
     const uint32_t b0 = base[t[0] + q], b1 = base[t[1] + q], b2 = base[t[2] + q], b3 = base[t[3] + q];
     const uint32_t W = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) & (0xFFFFFFFFu >> (w & 31u));
     const uint32_t x03 = (W + (W >> 24)) & 0xFFu;                  // byte arithmetic modulo 256: two's complement sum
-    send = (int)(x03 | (W & 0x00FFFF00u));
-    keep = send | (1 << 24);
+    const uint32_t v = x03 | (W & 0x00FFFF00u);
+    // every byte holds a value of -62..62: shifted left by one inside its byte it is twice that value (bit 7 = bit 6 = sign)
+    return (int)(((v << 1) & 0x00FEFEFEu) | tag);
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
-// Path metrics are scaled by 64, so their low six bits are free: they carry the keep(1)/receive(0) tags of the last
-// (up to) six steps of the lane's SURVIVOR — the tags travel with the path through the max.  Per step, 3 VALU issues:
-//   S = pm - 64 M                 (M = +-x0 +-x1 +-x2 +-x3, the branch metric of the lane's state)
-//   K = pm + 64 M + (1 << ph)     tag "kept at phase ph"; the bit is clear in pm, so the add sets it
-//   pm' = max(K, S of the butterfly partner lane)
-// After the six steps of a group (phases 0..5) the low six bits of a lane's metric are the history of ITS survivor
-// over those six steps; they are shifted into the lane's decision word (v_alignbit) and cleared.  A metric tie keeps
-// the own path, exactly as the textbook rule: K has bit ph set, S has not, and all higher tag bits are still zero.
-// Range: |metric| <= 27654 steps x 4 x 63 x 64 < 2^31.
-// Both 64 M + tag and 64 M come from the matrix core: six v_mfma_i32_4x4x4_16b_i8 per 12 steps (one per phase, see
-// tools/gen_acs32.py), otherwise idle, while the vector ALU is what bounds this kernel.  Their A operands are the
-// packed soft values of the chunk, staged in LDS memory by the lanes that gathered them (keep rows and send rows):
-// lane l reads row l mod 4.
+// Path metrics are scaled by 128; the low seven bits of a lane's value Q are a field that starts every group of six
+// steps at 63 and records the keep(1)/receive(0) history of the lane's SURVIVOR — it travels with the path through the
+// max.  Per step, 3 VALU issues and ONE number from the matrix core, X = 128 M + (1 << ph)
+// (M = +-x0 +-x1 +-x2 +-x3, the branch metric of the lane's state):
+//   S = Q - X                     sent to the butterfly partner: the field goes down by 1 << ph
+//   K = Q + X                     kept: the field goes up by 1 << ph
+//   Q' = max(K, S of the butterfly partner lane)
+// After the six steps of a group (phases 0..5) the field has gone from 63 to 2 x (the six tags of ITS survivor); it is
+// shifted into the lane's decision word (v_alignbit) and set back to 63 (v_and_or).  On the way it stays within 0..126
+// (down: 63 - (2^ph - 1) >= 2^ph; up: 63 + 63), so it never touches the metric, and a metric tie keeps the own path,
+// exactly as the textbook rule: the kept candidate's field is larger by at least 2 (tests/lane_model.py).
+// Range: |metric| <= 27654 steps x 4 x 31 x 128 < 2^31.
+// X comes from the matrix core: six v_mfma_i32_4x4x4_16b_i8 per 24 steps (one per phase, its four result rows are the
+// four groups of a decision word, see tools/gen_acs32.py), otherwise idle, while the vector ALU is what bounds this
+// kernel.  The A operands are the packed soft values of the chunk, staged in LDS memory by the lanes that gathered
+// them: lane l reads the row of group l mod 4.
 #include "dabx_acs32.inc"
 #define DABX_ACS_OPS                                                                                                \
     : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D)                                    \
     : [va] "v"(va), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),                          \
-      [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5])                                                             \
+      [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5]), [m128] "s"(-128)                                           \
     : "memory", DABX_ACS_CLOBBER
-// two groups = 12 steps; va = LDS byte address of the lane's A row: the chunk's first keep dword + 24 (lane & 1)
-// + (the send plane's offset if lane & 2)
-__device__ __forceinline__ void acs12(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
+// four groups = 24 steps = one decision word; va = LDS byte address of the lane's A row: the chunk's first dword + 24 (lane & 3)
+__device__ __forceinline__ void acs24(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
     int S, K, D;
-    asm volatile(DABX_ACS12_TEXT DABX_ACS_OPS);
+    asm volatile(DABX_ACS24_TEXT DABX_ACS_OPS);
 }
-// one group of six steps (the tail of a codeword)
+// one group of six steps (the tail of a codeword): only row 0 of the results is used
 __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
     int S, K, D;
@@ -836,7 +839,7 @@ __device__ __forceinline__ uint32_t walk96(const uint32_t wd[4], uint32_t A, uin
             o[k] |= rev >> n1;
             o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
         }
-        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (2 + 6 * (grp & 3))));
+        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (5 + 7 * (grp & 3))));
     }
     if (lane == 0) {
 #pragma unroll
@@ -872,7 +875,7 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
     for (int w = w_hi - 1; w >= B; --w) {
         const uint32_t *row = ring + (w & (VIT_RING - 1)) * 64;
 #pragma unroll
-        for (int gi = 3; gi >= 0; --gi) P = ~(P ^ (row[P & 63u] >> (2 + 6 * gi)));
+        for (int gi = 3; gi >= 0; --gi) P = ~(P ^ (row[P & 63u] >> (5 + 7 * gi)));
     }
     P &= 63u;
     O = (uint32_t)__builtin_amdgcn_readfirstlane((int)P);
@@ -887,13 +890,13 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 // of 192 bits (24 ms x 8 kbit/s; the FIC's 768), followed by the six tail steps.
 //   ring:   the wave's VIT_RING x 64 decision words in LDS: word w (the 24 steps of chunk w) of the lane with basis
 //           coordinates A at [(w mod VIT_RING) * 64 + A]; the tags of the chunk's i-th group of six steps sit at
-//           bits 2 + 6 i .. 7 + 6 i
+//           bits 5 + 7 i .. 10 + 7 i
 //   dec:    the codeword's block of global scratch, same layout without the modulus: touched only when the
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging buffer in LDS: keep rows at dword 0, send rows at dword 80 (64 each), the 19
-//           dwords of the address table at 144
+//   xs:     the wave's soft-value staging buffer in LDS: the A rows of a block's 48 steps at dword 0 (64 written), the 19
+//           dwords of the address table at 64
 __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
@@ -910,11 +913,11 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
             int neg = ((o >> (3 - j)) & 1) ^ u;
             kg |= (neg ? 0xC0 : 0x40) << (8 * j);          // -+64
         }
-        sk[ph] = kg | ((1 << ph) << 24);                   // fourth column: the tag of the phase
+        sk[ph] = kg | (1 << 24);                           // fourth column: 1 (the step's tag 1 << ph rides in the A row)
     }
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
-    int pm = lane == 0 ? 0 : PM_INIT * 64;
+    int pm = (lane == 0 ? 0 : PM_INIT * 128) + 63;              // metric x 128 + the field's start value
     const int nblk = nsteps / VIT_BLK;                           // full blocks of two chunks (even); the tail follows
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
     int w_dec = 0, w_ring = 0;                                   // first word not yet decoded / first word still in the ring
@@ -922,22 +925,21 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
     const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 48..63 fetch nothing
-    // A row of this lane: rows 0, 1 = keep of steps ph, ph + 6; rows 2, 3 = send of the same steps (LDS byte address:
-    // the low 32 bits of a shared pointer)
-    // the send plane starts 80 dwords in: the four addresses of a read (rows 0..3) then fall into four different LDS banks
-    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 1) + 320u * ((lane >> 1) & 1);
-    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 144;
+    // A row of this lane: row r = the step of group r of a 24-step chunk (LDS byte address: the low 32 bits of a shared
+    // pointer); the four addresses of a read (rows 0..3: six dwords apart) fall into four different LDS banks
+    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 64;
+    const uint32_t tag = (1u << (lane % 6)) << 24;               // a block is 48 steps: lane tau gathers a step of phase tau mod 6
     const int sh = src.slot_mask < 0 ? 4 : 0;
-    if (lane < 19) xs[144 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
-    int xk, xs_;
-    gather_step(src, tab, sh, step_word(info, tl, nsteps), xk, xs_);
+    if (lane < 19) xs[64 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
+    int xa = gather_step(src, tab, sh, step_word(info, tl, nsteps), tag);
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
-        xs[lane] = xk;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
-        xs[80 + lane] = xs_;                                     // operations execute in order, the previous block's reads are done
+        xs[lane] = xa;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
+                                                                 // operations execute in order, the previous block's reads are done
 #ifndef DABX_PROBE_NOGATHER
-        gather_step(src, tab, sh, wnext, xk, xs_);
+        xa = gather_step(src, tab, sh, wnext, tag);
         wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
 #endif
         const uint32_t va = va0;
@@ -947,13 +949,11 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
             A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
             break;
         }
-        acs12(pm, sk, va, lane_x32, bits);
-        acs12(pm, sk, va + 48u, lane_x32, bits);
-        ring[((2 * blk) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
+        acs24(pm, sk, va, lane_x32, bits);
+        ring[((2 * blk) & (VIT_RING - 1)) * 64 + coordA] = bits;
         bits = 0;
-        acs12(pm, sk, va + 96u, lane_x32, bits);
-        acs12(pm, sk, va + 144u, lane_x32, bits);
-        ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits >> 6;
+        acs24(pm, sk, va + 96u, lane_x32, bits);
+        ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits;
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
 #ifdef DABX_PROBE_NOTRACE
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][164];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][84];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     int *xs = xs_all[wave];
     uint32_t *ring = ring_all[wave];
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][164];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][84];
     __shared__ uint32_t ring_all[4][VIT_RING * 64];
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);

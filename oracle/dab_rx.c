@@ -25,8 +25,8 @@
 #define NFFT 2048
 #define BACKOFF 24          /* FFT window starts this many samples inside the guard */
 #define MW 16               /* integer carrier-offset search range (kHz)            */
-#define SOFT_EXP 16         /* soft-bit scale exponent, see demap()                 */
-#define SOFT_MAX 63.0f      /* soft bits are limited to +-63: the sum of two fits a byte (the GPU packs x0 + x3) */
+#define SOFT_EXP 15         /* soft-bit scale exponent, see demap()                 */
+#define SOFT_MAX 31.0f      /* soft bits are limited to +-31: twice the sum of two fits a byte (the GPU packs 2 (x0 + x3)) */
 #define PM_INIT (-1000000)  /* path metric of states other than 0 at trellis start  */
 #define LOCK_THR 48.0f
 #define EARLY_SPAN 400      /* the first path may lead the strongest one by up to this many samples ...   */

@@ -14,7 +14,7 @@ o = np.stack([ob.fft(v) for v in x]).astype(np.complex64)
 print("fft bit-exact:", np.array_equal(g.view(np.uint32), o.view(np.uint32)), "max abs diff", np.abs(g - o).max())
 # Viterbi linear
 for kind, prof, ncoded in ((0, (0, 3, 64), 2304), (1, (0, 3, 64), 3072), (1, (0, 1, 8), 768), (1, (1, 4, 32), 960)):
-    soft = rng.integers(-63, 64, (5, ncoded)).astype(np.int8)
+    soft = rng.integers(-31, 32, (5, ncoded)).astype(np.int8)
     gv = ctx.viterbi(soft, kind, *prof)
     ov = np.stack([ob.decode_linear(s, kind, *prof) for s in soft])
     print("viterbi", kind, prof, "exact:", np.array_equal(gv, ov), (gv != ov).sum())

@@ -90,7 +90,12 @@ def scenario(k, rng):
         decs.append([ob.SuperframeDecoder(kb) if p else None for kb, p in zip(kbps, plus)])
     n_sf_total = 0
     for step in range(steps):
-        ctx.process(F)
+        try:
+            ctx.process(F)
+        except aa.DabxError as e:                # a drifting clock or a re-acquisition can use the recording up early: both sides must say so
+            assert "not enough samples" in str(e), (k, step, str(e))
+            assert any(orc.process(F)["rc"] == -1 for orc in oracles), (k, step, "underrun on the GPU only")
+            break
         for s, orc in enumerate(oracles):
             o = orc.process(F)
             assert o["rc"] in (0, F), (k, "rc")

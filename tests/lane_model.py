@@ -41,25 +41,28 @@ def sig_tables():
 
 
 def decode(x4):
-    """x4: [nsteps, 4] int soft values (0 = punctured, |x| <= 63), nsteps a multiple of 6.  Returns decoded bits [nsteps].
+    """x4: [nsteps, 4] int soft values (0 = punctured, |x| <= 31), nsteps a multiple of 6.  Returns decoded bits [nsteps].
 
-    Mirrors viterbi_wave(): path metrics are scaled by 64 and the low six bits of a metric carry the keep/receive
-    tags of the last (up to) six steps of ITS survivor path (bit ph = 1: kept at the step of phase ph), so the tags
-    travel with the path through the max.  Both candidates come straight from the matrix core: with the soft values
-    packed as (x0 + x3, x1, x2, 1) — generators 0 and 3 of the DAB mother code are the same polynomial, and the sum
-    fits a byte because |x| <= 63 — and the lane's signs as (+-64, +-64, +-64, 1 << ph), the keep row gives
-    64 M + tag and the row with a 0 in the last column gives 64 M, which is subtracted.  At the end of a
-    group of six steps the six tags go into the lane's decision word (four groups = 24 steps per word) and are
-    cleared.  A tie keeps the own path: the kept candidate has its tag bit set, the received one does not, all
-    higher tag bits are zero.  The traceback walks six steps per look-up: position ^= ~tags."""
+    Mirrors viterbi_wave().  Path metrics are scaled by 128; the low seven bits of a lane's value Q carry a field that
+    starts every group of six steps at 63.  One number per step and lane comes from the matrix core: with the soft values
+    packed as (2 (x0 + x3), 2 x1, 2 x2, 1 << ph) — generators 0 and 3 of the DAB mother code are the same polynomial, and
+    twice the sum fits a byte because |x| <= 31 — and the lane's signs as (+-64, +-64, +-64, 1), X = 128 M + (1 << ph).
+    The kept candidate is Q + X, the one sent to the butterfly partner Q - X: the field of a survivor goes up by 1 << ph
+    where it was kept and down by 1 << ph where it was received, so after the six steps it has gone from 63 to
+    2 * (sum of the kept steps' 1 << ph): bits 1..6 are the keep/receive tags of ITS survivor path, they travelled with
+    the path through the max.  The field never leaves 0..126 (63 - (2^ph - 1) >= 2^ph on the way down, 63 + 63 on the way
+    up), so it never touches the metric, and a metric tie keeps the own path: the kept candidate's field is larger by at
+    least 2.  At the end of a group the field goes into the lane's decision word (four groups = 24 steps per word) and
+    is set back to 63.  The traceback walks six steps per look-up: position ^= ~tags."""
     nsteps = len(x4)
-    assert nsteps % 6 == 0 and np.abs(x4).max(initial=0) <= 63
+    assert nsteps % 6 == 0 and np.abs(x4).max(initial=0) <= 31
     sig = sig_tables()
     assert np.array_equal(sig[:, :, 0], sig[:, :, 3])                  # x0 and x3: the same generator (133 octal)
     lanes = np.arange(64)
     coordA = lanes ^ (((lanes >> 2) & 1) * 3)
-    pm = np.full(64, PM_INIT * 64, dtype=np.int64)
-    pm[0] = 0
+    Q = np.full(64, PM_INIT * 128, dtype=np.int64)
+    Q[0] = 0
+    Q += 63
     G = nsteps // 6
     nwords = (G + 3) // 4
     dec = np.zeros((nwords, 64), dtype=np.uint64)
@@ -70,25 +73,27 @@ def decode(x4):
             for ph in range(6):
                 t = (4 * w + gi) * 6 + ph
                 x = x4[t].astype(np.int64)
-                a_keep = np.array([x[0] + x[3], x[1], x[2], 1])        # MFMA A rows (int8 each)
-                a_send = np.array([x[0] + x[3], x[1], x[2], 0])
-                assert np.abs(a_keep).max() <= 127
-                b = np.concatenate([64 * sig[ph][:, :3], np.full((64, 1), 1 << ph)], axis=1)   # MFMA B column of every lane
-                keep = pm + b @ a_keep
-                send = pm - b @ a_send
+                a = np.array([2 * (x[0] + x[3]), 2 * x[1], 2 * x[2], 1 << ph])                 # MFMA A row (int8 each)
+                assert np.abs(a).max() <= 127
+                b = np.concatenate([64 * sig[ph][:, :3], np.ones((64, 1), dtype=np.int64)], axis=1)   # MFMA B column of every lane
+                X = b @ a
+                keep = Q + X
+                send = Q - X
                 recv = send[lanes ^ XV[ph]]
-                pm = np.maximum(keep, recv)
-                assert np.abs(pm).max() < 2 ** 31
-            bits = (((pm & 63).astype(np.uint64)) << np.uint64(26)) | (bits >> np.uint64(6))     # v_alignbit_b32 bits, pm, bits, 6
-            pm = pm & ~63
-        bits >>= np.uint64(30 - 6 * ng)
+                Q = np.maximum(keep, recv)
+                assert np.abs(Q).max() < 2 ** 31 and ((Q & 127) <= 126).all()
+            field = Q & 127
+            assert (field & 1 == 0).all()
+            bits = (field.astype(np.uint64) << np.uint64(25)) | (bits >> np.uint64(7))           # v_alignbit_b32 bits, Q, bits, 7
+            Q = (Q & ~127) | 63                                                                # v_and_or_b32
+        bits >>= np.uint64(7 * (4 - ng))                    # group gi of the word: field at bit 4 + 7 gi, its tags at 5 + 7 gi
         dec[w, coordA] = bits
     out = np.zeros(nsteps, dtype=np.uint8)
     A = 0
     for w in range(nwords - 1, -1, -1):
         ng = min(4, G - 4 * w)
         for gi in range(ng - 1, -1, -1):
-            h = (int(dec[w, A]) >> (2 + 6 * gi)) & 63
+            h = (int(dec[w, A]) >> (5 + 7 * gi)) & 63
             for q in range(6):
                 out[(4 * w + gi) * 6 + q] = (A >> q) & 1
             A ^= (~h) & 63

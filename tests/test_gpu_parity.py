@@ -26,10 +26,10 @@ def test_viterbi_bit_exact(gpu_ctx_factory, kind, prof):
     ctx = gpu_ctx_factory(n_streams=1, max_frames=1, ring_frames=4)
     n_coded = 2304 if kind == 0 else ob.any_profile(*prof).n_coded
     rng = np.random.default_rng(hash(prof) & 0xFFFF)
-    soft = rng.integers(-63, 64, (9, n_coded)).astype(np.int8)        # the soft-bit contract: |x| <= 63
+    soft = rng.integers(-31, 32, (9, n_coded)).astype(np.int8)        # the soft-bit contract: |x| <= 31
     soft[1] = 0                                   # all ties
     soft[2] = rng.integers(-1, 2, n_coded)        # many ties
-    soft[3] = 63                                  # saturated, all-zero codeword
+    soft[3] = 31                                  # saturated, all-zero codeword
     g = ctx.viterbi(soft, kind, *prof)
     o = np.stack([ob.decode_linear(s, kind, *prof) for s in soft])
     assert np.array_equal(g, o)
