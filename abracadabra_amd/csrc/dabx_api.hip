@@ -864,6 +864,9 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     const int nsteps = p.steps();
     const size_t words = static_cast<size_t>((nsteps / 24 + 1) * 64);
     if (nsteps % 48 != 6) return DABX_E_PROFILE;             // every DAB codeword: 48 k + 6 trellis steps
+    // the soft-bit contract of the decoder (twice the sum of two soft bits must fit a byte): refuse what breaks it
+    for (size_t i = 0, n = static_cast<size_t>(n_cw) * p.n_coded; i < n; ++i)
+        if (soft[i] > 31 || soft[i] < -31) return DABX_E_ARG;
     DevTmp t_soft, t_info, t_scr, t_out;
     HIPCHK(hipMalloc(&t_soft.p, static_cast<size_t>(n_cw) * p.n_coded + 64));
     HIPCHK(hipMalloc(&t_info.p, info.size() * 4));

@@ -178,7 +178,7 @@ DABX_API int dabx_get_fib_counts(dabx_ctx *ctx, int64_t *ok, int64_t *bad);
 /* Stage-level entry points (BASELINE config "FFT + DQPSK demap kernel only",
  * and unit parity tests).  Host pointers.
  *   dabx_fft2048: n_vec vectors of 2048 complex float (re,im interleaved), natural bin order out
- *   dabx_viterbi: n_cw punctured codewords of one profile, soft bits linear in memory, |soft| <= 31 (the range the
+ *   dabx_viterbi: n_cw punctured codewords of one profile, soft bits linear in memory, |soft| <= 31, else DABX_E_ARG (the range the
  *                 demapper produces: the decoder adds the two soft bits of the repeated generator in one byte);
  *                 kind 0 = FIC codeword (2304 soft -> 96 bytes), 1 = EEP(option, level, kbps) */
 DABX_API int dabx_fft2048(dabx_ctx *ctx, const float *in, float *out, int n_vec);

@@ -9,8 +9,8 @@ ctx = aa.Context(n_streams=1, max_frames=1, ring_frames=4)
 rng = np.random.default_rng(1)
 for kind, prof in ((0, (0, 3, 64)), (1, (0, 3, 64)), (1, (0, 1, 8)), (1, (0, 3, 1152))):
     n_coded = 2304 if kind == 0 else ob.any_profile(*prof).n_coded
-    soft = rng.integers(-63, 64, (6, n_coded)).astype(np.int8)
-    soft[0] = 63
+    soft = rng.integers(-31, 32, (6, n_coded)).astype(np.int8)
+    soft[0] = 31
     soft[1] = 0
     soft[2] = rng.integers(-1, 2, n_coded)
     # a clean codeword: encode random bits is not available here; use strong random soft (still a valid test vs oracle)

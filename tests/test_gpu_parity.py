@@ -33,6 +33,9 @@ def test_viterbi_bit_exact(gpu_ctx_factory, kind, prof):
     g = ctx.viterbi(soft, kind, *prof)
     o = np.stack([ob.decode_linear(s, kind, *prof) for s in soft])
     assert np.array_equal(g, o)
+    soft[4, 17] = 32                              # outside the soft-bit contract: refused, not decoded wrongly
+    with pytest.raises(aa.DabxError):
+        ctx.viterbi(soft, kind, *prof)
 
 
 def _run_pair(ctx, streams, steps, frames, subs):
