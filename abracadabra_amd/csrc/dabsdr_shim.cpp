@@ -87,6 +87,8 @@ struct dabsdr_s {
     uint32_t frequency = 0;
     int gain_shift = 0;                  // float -> s16 scaling: x * 2^gain_shift
     bool gain_set = false;
+    bool locked_hint = false;            // the last step left the receiver locked: whole frames are collected; while it is not, every chunk is
+                                         // handed on at once, so that the lock comes as early as the samples allow (2.1 frames, not 3)
     std::vector<float> first_frame;      // input held back until one whole frame has been seen (the gain is fixed on it)
     int16_t *frame_s16 = nullptr;        // the frame being collected for the GPU: page-locked, so its copy needs no synchronisation
     float frame_peak = 0.0f;             // |sample| peak of the frame in progress (gain hysteresis)
@@ -287,7 +289,7 @@ void handle_request(dabsdr_s *h, const Request &r)
             notify(h, DABSDR_NID_TUNE, DABSDR_NSTAT_SUCCESS, &f, 0);
         } else {
             h->frequency = r.a;
-            h->gain_set = false;
+            h->gain_set = false; h->locked_hint = false;
             h->first_frame.clear();
             h->msc_stride = 0;
             // a fresh context state: drop everything buffered so far
@@ -625,6 +627,7 @@ void after_step(dabsdr_s *h)
     int good = 0;
     for (int i = 0; i < 12; ++i)
         if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
+    h->locked_hint = st.locked != 0;
     const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
     // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy.
     // The null symbol may carry TII carriers (32 of 1536), so its noise level is taken from the median
@@ -796,6 +799,16 @@ void worker_loop(dabsdr_s *h)
         if (!h->frame_s16) h->frame_s16 = static_cast<int16_t *>(dabx_alloc_pinned(2 * static_cast<size_t>(DABX_FRAME_SAMPLES) * sizeof(int16_t)));
         if (!h->frame_s16) return;
         bool complete = true;
+        const bool chunked = !h->locked_hint;                            // acquiring: chunk by chunk (synchronous copies, steps in between)
+        auto run_steps = [h]() -> bool {
+            bool stepped = false;
+            while (!h->exit_req.load() && h->ctx && dabx_frames_available(h->ctx) >= 1) {
+                if (dabx_process(h->ctx, 1) != DABX_OK) break;           // waits for the queued copy of the frame buffer
+                stepped = true;
+                after_step(h);
+            }
+            return stepped;
+        };
         for (int got = 0; got < DABX_FRAME_SAMPLES; got += kPullChunk) {
             if (h->exit_req.load() || (got && !serve(false))) { if (!h->exit_req.load()) return; complete = false; break; }
             if (h->frequency == 0 || !h->ctx) { complete = false; break; }
@@ -810,19 +823,20 @@ void worker_loop(dabsdr_s *h)
                     convert(h, h->first_frame.data() + o, h->frame_s16 + o, 2 * kPullChunk);
                 h->first_frame.clear(); h->first_frame.shrink_to_fit();
                 (void)dabx_push(h->ctx, 0, h->frame_s16, DABX_FRAME_SAMPLES, DABX_SRC_PINNED);
+                (void)dabx_flush_copies(h->ctx);                        // the buffer is refilled next
                 complete = false;                                       // this frame has gone; start collecting the next one
                 break;
             }
             convert(h, h->fbuf.data(), h->frame_s16 + 2 * static_cast<size_t>(got), 2 * kPullChunk);
+            if (chunked) {
+                if (dabx_push(h->ctx, 0, h->frame_s16 + 2 * static_cast<size_t>(got), kPullChunk, DABX_SRC_HOST) != DABX_OK) { complete = false; break; }
+                (void)run_steps();
+                if (!h->ctx) { complete = false; break; }                // a reset inside after_step
+            }
         }
+        if (chunked) continue;
         if (complete && h->gain_set && h->first_frame.empty() && dabx_push(h->ctx, 0, h->frame_s16, DABX_FRAME_SAMPLES, DABX_SRC_PINNED) != DABX_OK) continue;
-        bool stepped = false;
-        while (!h->exit_req.load() && dabx_frames_available(h->ctx) >= 1) {
-            if (dabx_process(h->ctx, 1) != DABX_OK) break;       // waits for the queued copy of the frame buffer
-            stepped = true;
-            after_step(h);
-        }
-        if (!stepped && h->ctx) dabx_flush_copies(h->ctx);       // the frame buffer is refilled next: its copy must have left it
+        if (!run_steps() && h->ctx) dabx_flush_copies(h->ctx);   // the frame buffer is refilled next: its copy must have left it
     }
 }
 
