@@ -146,3 +146,29 @@ def test_gpu_lock_time_frequency_offset_and_input_scale(cfo, scale):
         assert cl["comps"] == [dict(scids=0, subch=0, addr=0, size=48, prot=8, ps=2, tmid=0, ascty=63, kbps=64, fec=0)]
     finally:
         host.close()
+
+
+@pytest.mark.gpu
+def test_gpu_several_handles_in_one_process():
+    """the reference accepts several handles per process if each gets its own function pointers (the input
+    callback carries no context); all lock with fibErr = 0.  Three handles, three different ensembles, running at once."""
+    from legacy_host import NID, LegacyHost
+    sub = [[0, 0, 3, 64]]
+    hosts = []
+    try:
+        for k in range(3):
+            iq, _, _ = ob.tx_generate(seed=120 + k, eid=0x2000 + k, n_frames=16, subch=sub, delay=1000 + 3000 * k, snr_db=25.0, cfo_hz=400.0 * (k - 1))
+            hosts.append(LegacyHost(iq.astype(np.float32) - 128.0, gate_at=10 * 196608))
+        for h in hosts:
+            h.tune(periodic=0)
+        for k, h in enumerate(hosts):
+            h.wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)
+            per = h.wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e.get("level") == 3 and e["at"] >= 8 * 196608)[-1]
+            assert per["fib_err"] == 0 and abs(per["foff"] / 10.0 - 400.0 * (k - 1)) < 1.0
+            h.L.dabsdrRequest_GetEnsemble(h.handle)
+            ens = h.wait_for(lambda e: e["nid"] == NID["ENSEMBLE_INFO"] and e["status"] == 0)[-1]
+            assert ens["ueid"] == 0x00E20000 | (0x2000 + k)
+    finally:
+        for h in hosts:
+            h.open_gate()
+            h.close()
