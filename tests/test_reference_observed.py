@@ -10,6 +10,7 @@ reference-derived facts available for this path; they narrow the parity gap with
 """
 import ctypes as C
 import math
+import time
 
 import numpy as np
 import pytest
@@ -172,3 +173,35 @@ def test_gpu_several_handles_in_one_process():
         for h in hosts:
             h.open_gate()
             h.close()
+
+
+@pytest.mark.gpu
+def test_gpu_noise_input_tune_and_idle_sequences():
+    """nothing is pulled before Tune; Tune(f) answers TUNE(f) then RESET(0) and the library reads input without
+    ever locking on noise; Tune(0) answers RESET then TUNE(0), after which it is idle (no more input calls)."""
+    from legacy_host import NID, LegacyHost
+    rng = np.random.default_rng(5)
+    host = LegacyHost(rng.uniform(-128.0, 128.0, 2 * 40 * 196608).astype(np.float32))
+    try:
+        time.sleep(0.3)
+        assert host.pos == 0 and not host.events                     # dabsdr() is running, nothing tuned: no input calls, no notifications
+        host.tune(periodic=0)
+        host.wait_for(lambda e: e["nid"] == NID["RESET"])
+        seq = [(e["nid"], e.get("freq"), e.get("flag")) for e in host.events if e["nid"] in (NID["TUNE"], NID["RESET"])]
+        assert seq[:2] == [(NID["TUNE"], 225648, None), (NID["RESET"], None, 0)]
+        t0 = time.time()
+        while host.pos < 2 * 12 * 196608 and time.time() - t0 < 30:  # it reads on and on ...
+            time.sleep(0.01)
+        assert host.pos >= 2 * 12 * 196608
+        assert not [e for e in host.events if e["nid"] == NID["SYNC_STATUS"] and e.get("level", 0) > 0]      # ... and never locks
+        n0 = len(host.events)
+        host.L.dabsdrRequest_Tune(host.handle, 0)
+        host.wait_for(lambda e: e["nid"] == NID["TUNE"] and e.get("freq") == 0)
+        tail = [(e["nid"], e.get("freq"), e.get("flag")) for e in host.events[n0:] if e["nid"] in (NID["TUNE"], NID["RESET"])]
+        assert tail == [(NID["RESET"], None, 0), (NID["TUNE"], 0, None)]
+        time.sleep(0.2)
+        p = host.pos
+        time.sleep(0.3)
+        assert host.pos == p                                          # idle
+    finally:
+        host.close()
