@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_null_search(DevCtx C)
 // One workgroup per (stream, frame): guard correlation -> fractional CFO, PRS FFT,
 // optional integer-CFO search, impulse response peak -> window position.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
+__global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
 {
     const int s = blockIdx.x / n_frames, f = blockIdx.x % n_frames, t = threadIdx.x;
     const DevState &st = C.state[s];
@@ -377,8 +377,11 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
     const int wide = !st.locked;
     // frame f is expected where the tracked sampling-clock drift puts it (no drift is known while acquiring)
     int64_t pos_f = st.pos + (int64_t)f * TF + (wide ? 0 : (((int64_t)f * st.slope) >> 16));
-    Twiddles tw;
-    load_twiddles(tw, T.W, t);
+    // twiddles of passes B and C in LDS, like k_demod: at <= 128 registers four workgroups share a CU instead of two, and this
+    // kernel is one long chain of dependent phases per frame — latency, not throughput
+    __shared__ float2 twl[TWL];
+    cf twa[7];
+    load_twiddles_lds(twa, twl, T.W, t);
     cf v[8];
     int32_t inc = 0;
 
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
     const int64_t w0 = pos_f + TNULL + TG - BACKOFF;
     const int64_t w0i = wrap(w0, C.ring_len);
     load_window<FMT>(v, T, ring, C.ring_len, w0i, 0u, inc, t);
-    fft2048(v, buf, t, tw);
+    fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
     int m_best = 0;
     if (wide) {
         // spectrum to natural order for the shifted differential correlation
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         inc = inc + m_best * (1 << 21);
         __syncthreads();
         load_window<FMT>(v, T, ring, C.ring_len, w0i, 0u, inc, t);
-        fft2048(v, buf, t, tw);
+        fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
     }
     // optional signal spectrum of the last frame (reference: dabsdrSpectrumCBFunc_t, dabsdr.h:393):
     // linear power of the un-normalised 2048-point FFT, natural bin order (a second pass overwrites the first)
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { float2 x = nat[t + 256 * j]; v[j] = {x.x, x.y}; }
     __syncthreads();
-    fft2048(v, buf, t, tw);
+    fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
     float acc = 0.0f, peak = -1.0f;
     int pidx = 0;
 #pragma unroll
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256) void k_sync(DevCtx C, int n_frames)
         __syncthreads();
         const int64_t n0 = pos_f + (TNULL - TU) / 2;
         load_window<FMT>(v, T, ring, C.ring_len, wrap(n0, C.ring_len), 0u, inc, t);
-        fft2048(v, buf, t, tw);
+        fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float a = v[e].r * v[e].r, b = v[e].i * v[e].i;
