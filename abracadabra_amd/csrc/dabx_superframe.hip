@@ -94,6 +94,7 @@ __global__ __launch_bounds__(SF_THREADS, 4) void k_superframe(DevCtx C, const De
                                                     uint8_t *data, const uint8_t *__restrict__ gf_tab, int n_frames, int max_rec)
 {
     __shared__ uint8_t t_exp[512], t_log[256];
+    __shared__ uint8_t t_mul[9 * 256];                   // v * alpha^r, r = 1..9
     __shared__ uint16_t t_crc[256], t_fire[256], t_shift[16];
     __shared__ uint16_t ch_crc[SF_BATCH * 96];           // CRC of every 32-byte chunk of the access units
     __shared__ int16_t ch_first[SF_BATCH * 8 + 1];       // first chunk of access unit a of window w at [8 w + a]; [8 nb] = total
@@ -123,6 +124,10 @@ __global__ __launch_bounds__(SF_THREADS, 4) void k_superframe(DevCtx C, const De
         t_fire[v] = static_cast<uint16_t>(f);
     }
     __syncthreads();
+    for (int idx = t; idx < 9 * 256; idx += SF_THREADS) {
+        const int r = (idx >> 8) + 1, v = idx & 255;
+        t_mul[idx] = v ? t_exp[t_log[v] + r] : 0;
+    }
     if (t < 16) {                                        // x^t * x^(8*32) mod the CRC polynomial: moves a CRC past a 32-byte chunk
         unsigned c = 1u << t;
         for (int k = 0; k < CRC_CHUNK; ++k) c = ((c << 8) ^ t_crc[(c >> 8) & 0xFF]) & 0xFFFF;
@@ -170,21 +175,32 @@ __global__ __launch_bounds__(SF_THREADS, 4) void k_superframe(DevCtx C, const De
             }
         }
         __syncthreads();
-        // ---- RS(120,110): syndrome r of code word j of window w is item (w, 10 j + r)
-        for (int q = t; q < nb * 10 * s; q += SF_THREADS) {
-            // S_r = sum_k c_k alpha^(r (119 - k)): 120 independent table look-ups instead of a Horner chain
-            const int w = q / (10 * s), jr = q - w * 10 * s, j = jr / 10, r = jr % 10;
-            const uint8_t *sf = sfa + w * SF_WIN;
-            unsigned acc = 0;
-            int e = (r * 119) % 255;
-#pragma unroll 8
-            for (int k = 0; k < 120; ++k) {              // branch-free so that the look-ups of several terms overlap
-                const unsigned cb = sf[j + k * s];
-                acc ^= cb ? t_exp[t_log[cb] + e] : 0u;
-                e -= r;
-                e += e < 0 ? 255 : 0;
+        // ---- RS(120,110) syndromes S_r = sum_k c_k alpha^(r (119 - k)), r = 0..9, of code word j of window w.  Four lanes
+        // share a code word, 30 bytes each: a lane runs the ten Horner chains of its bytes side by side (one look-up in the
+        // "times alpha^r" table and one xor per term: ten independent chains hide the look-up latency; S_0 is a plain xor),
+        // moves its partial results to their place in the code word (times alpha^(30 r (3 - segment))) and the four are
+        // xor-ed across the lanes.  (Before: one log and one antilog look-up per term, 20 per byte instead of 10.)
+        for (int q = t; q < nb * s * 4; q += SF_THREADS) {
+            const int cw = q >> 2, seg = q & 3, w = cw / s, j = cw - w * s;
+            const uint8_t *sf = sfa + w * SF_WIN + j + 30 * seg * s;
+            unsigned a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < 30; ++k) {
+                const unsigned cb = sf[k * s];
+                a[0] ^= cb;
+#pragma unroll
+                for (int r = 1; r < 10; ++r) a[r] = t_mul[(r - 1) * 256 + a[r]] ^ cb;
             }
-            synd[w * 240 + jr] = static_cast<uint8_t>(acc);
+#pragma unroll
+            for (int r = 1; r < 10; ++r) a[r] = a[r] ? t_exp[t_log[a[r]] + (30 * r * (3 - seg)) % 255] : 0u;
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                a[r] ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[r], 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+                a[r] ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[r], 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+            }
+            if (seg == 0) {
+#pragma unroll
+                for (int r = 0; r < 10; ++r) synd[w * 240 + 10 * j + r] = static_cast<uint8_t>(a[r]);
+            }
         }
         __syncthreads();
         if (t < s)
