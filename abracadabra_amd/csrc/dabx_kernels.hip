@@ -874,12 +874,23 @@ __device__ __forceinline__ void trace_words(const uint32_t *ring, const uint32_t
 // later trellis state passes through it: the words before B can be decoded now, exactly.
 __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi, int B, int coordA, uint32_t &O)
 {
-    uint32_t P = (uint32_t)coordA;
+    // The walk runs on LDS byte addresses: a = row + 4 P.  The rows are 256 bytes and 256-byte aligned, so the position sits
+    // in bits 2..7 of a, and "P = ~(P ^ tags)" is one xor of those bits with the complemented tags (which the decision word
+    // holds at bits 5 + 7 g, i.e. times four at bits 3 + 7 g): a shift and one three-operand logic instruction per six steps.
+    const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // low 32 bits of a shared pointer = the LDS address
+    uint32_t a = ring_a + (uint32_t)((w_hi - 1) & (VIT_RING - 1)) * 256u + ((uint32_t)coordA << 2);
     for (int w = w_hi - 1; w >= B; --w) {
-        const uint32_t *row = ring + (w & (VIT_RING - 1)) * 64;
-#pragma unroll
-        for (int gi = 3; gi >= 0; --gi) P = ~(P ^ (row[P & 63u] >> (5 + 7 * gi)));
+        uint32_t x;
+        // a ^= ~(word(a) >> (3 + 7 g)) & 0xFC for g = 3, 2, 1, 0 (v_bitop3 with the table of s0 ^ (~s1 & s2)); written out: the
+        // compiler keeps two copies of the address and spends four instructions per group
+        asm volatile("ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 24, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 17, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 10, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 3, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2"
+                     : [a] "+v"(a), [x] "=&v"(x) : [m] "s"(0xFC) : "memory");
+        a += (uint32_t)(((w - 1) & (VIT_RING - 1)) - (w & (VIT_RING - 1))) * 256u;      // to the row of the word before
     }
+    uint32_t P = a >> 2;
     P &= 63u;
     O = (uint32_t)__builtin_amdgcn_readfirstlane((int)P);
 #ifdef DABX_PROBE_FORCE_MERGE
@@ -993,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][84];
-    __shared__ uint32_t ring_all[4][VIT_RING * 64];
+    __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
     int *xs = xs_all[wave];
     uint32_t *ring = ring_all[wave];
     const DevWork w = work[wi];
@@ -1022,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][84];
-    __shared__ uint32_t ring_all[4][VIT_RING * 64];
+    __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
 }
