@@ -803,19 +803,22 @@ __device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *ta
 #include "dabx_acs32.inc"
 #define DABX_ACS_OPS                                                                                                \
     : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D)                                    \
-    : [va] "v"(va), [ad] "v"(lane_x32), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),                          \
+    : [va] "v"(va), [ad] "v"(lane_x32), [wa] "v"(wa), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),            \
       [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5]), [m128] "s"(-128)                                           \
     : "memory", DABX_ACS_CLOBBER
-// four groups = 24 steps = one decision word; va = LDS byte address of the lane's A row: the chunk's first dword + 24 (lane & 3)
-__device__ __forceinline__ void acs24(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
+// four groups = 24 steps = one decision word, written byte by byte to the LDS address wa; va = LDS byte address of the lane's
+// A row: the chunk's first dword + 24 (lane & 3)
+__device__ __forceinline__ void acs24(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t wa)
 {
     int S, K, D;
+    uint32_t bits = 0;
     asm volatile(DABX_ACS24_TEXT DABX_ACS_OPS);
 }
 // one group of six steps (the tail of a codeword): only row 0 of the results is used
 __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
     int S, K, D;
+    const uint32_t wa = 0;
     asm volatile(DABX_ACS6_TEXT DABX_ACS_OPS);
 }
 #undef DABX_ACS_OPS
@@ -842,7 +845,7 @@ __device__ __forceinline__ uint32_t walk96(const uint32_t wd[4], uint32_t A, uin
             o[k] |= rev >> n1;
             o[k + 1] |= (rev & ((1u << n1) - 1u)) << (32 - n1);
         }
-        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (5 + 7 * (grp & 3))));
+        A = ~(A ^ ((uint32_t)__builtin_amdgcn_readlane((int)wd[grp >> 2], (int)A) >> (1 + 8 * (grp & 3))));
     }
     if (lane == 0) {
 #pragma unroll
@@ -876,17 +879,17 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 {
     // The walk runs on LDS byte addresses: a = row + 4 P.  The rows are 256 bytes and 256-byte aligned, so the position sits
     // in bits 2..7 of a, and "P = ~(P ^ tags)" is one xor of those bits with the complemented tags (which the decision word
-    // holds at bits 5 + 7 g, i.e. times four at bits 3 + 7 g): a shift and one three-operand logic instruction per six steps.
+    // holds at bits 1 + 8 g, i.e. times four at bits 8 g - 1): a shift and one three-operand logic instruction per six steps.
     const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // low 32 bits of a shared pointer = the LDS address
     uint32_t a = ring_a + (uint32_t)((w_hi - 1) & (VIT_RING - 1)) * 256u + ((uint32_t)coordA << 2);
     for (int w = w_hi - 1; w >= B; --w) {
         uint32_t x;
-        // a ^= ~(word(a) >> (3 + 7 g)) & 0xFC for g = 3, 2, 1, 0 (v_bitop3 with the table of s0 ^ (~s1 & s2)); written out: the
+        // a ^= ~(word(a) >> (8 g - 1)) & 0xFC for g = 3, 2, 1, 0 (v_bitop3 with the table of s0 ^ (~s1 & s2)); written out: the
         // compiler keeps two copies of the address and spends four instructions per group
-        asm volatile("ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 24, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
-                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 17, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
-                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 10, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
-                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 3, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2"
+        asm volatile("ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 23, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 15, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 7, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %[x], 1, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2"
                      : [a] "+v"(a), [x] "=&v"(x) : [m] "s"(0xFC) : "memory");
         a += (uint32_t)(((w - 1) & (VIT_RING - 1)) - (w & (VIT_RING - 1))) * 256u;      // to the row of the word before
     }
@@ -903,8 +906,8 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 // Decode one terminated codeword with the calling wave.  Every DAB codeword has 192 k + 6 steps: n_in is a multiple
 // of 192 bits (24 ms x 8 kbit/s; the FIC's 768), followed by the six tail steps.
 //   ring:   the wave's VIT_RING x 64 decision words in LDS: word w (the 24 steps of chunk w) of the lane with basis
-//           coordinates A at [(w mod VIT_RING) * 64 + A]; the tags of the chunk's i-th group of six steps sit at
-//           bits 5 + 7 i .. 10 + 7 i
+//           coordinates A at [(w mod VIT_RING) * 64 + A]; byte i of the word is the field of the chunk's i-th group of six
+//           steps: its tags at bits 1 + 8 i .. 6 + 8 i (bits 8 i and 7 + 8 i are not part of it)
 //   dec:    the codeword's block of global scratch, same layout without the modulus: touched only when the
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
@@ -943,6 +946,7 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     // pointer); the four addresses of a read (rows 0..3: six dwords apart) fall into four different LDS banks
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);
     const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 64;
+    const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // LDS byte address of the wave's decision ring
     const uint32_t tag = (1u << (lane % 6)) << 24;               // a block is 48 steps: lane tau gathers a step of phase tau mod 6
     const int sh = src.slot_mask < 0 ? 4 : 0;
     if (lane < 19) xs[64 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
@@ -963,11 +967,8 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
             A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
             break;
         }
-        acs24(pm, sk, va, lane_x32, bits);
-        ring[((2 * blk) & (VIT_RING - 1)) * 64 + coordA] = bits;
-        bits = 0;
-        acs24(pm, sk, va + 96u, lane_x32, bits);
-        ring[((2 * blk + 1) & (VIT_RING - 1)) * 64 + coordA] = bits;
+        acs24(pm, sk, va, lane_x32, ring_a + (uint32_t)(((2 * blk) & (VIT_RING - 1)) * 256 + 4 * coordA));
+        acs24(pm, sk, va + 96u, lane_x32, ring_a + (uint32_t)(((2 * blk + 1) & (VIT_RING - 1)) * 256 + 4 * coordA));
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
 #ifdef DABX_PROBE_NOTRACE

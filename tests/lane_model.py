@@ -52,8 +52,8 @@ def decode(x4):
     2 * (sum of the kept steps' 1 << ph): bits 1..6 are the keep/receive tags of ITS survivor path, they travelled with
     the path through the max.  The field never leaves 0..126 (63 - (2^ph - 1) >= 2^ph on the way down, 63 + 63 on the way
     up), so it never touches the metric, and a metric tie keeps the own path: the kept candidate's field is larger by at
-    least 2.  At the end of a group the field goes into the lane's decision word (four groups = 24 steps per word) and
-    is set back to 63.  The traceback walks six steps per look-up: position ^= ~tags."""
+    least 2.  At the end of a group the field is stored as a byte of the lane's decision word (four groups = 24 steps per word)
+    and set back to 63.  The traceback walks six steps per look-up: position ^= ~tags."""
     nsteps = len(x4)
     assert nsteps % 6 == 0 and np.abs(x4).max(initial=0) <= 31
     sig = sig_tables()
@@ -84,16 +84,15 @@ def decode(x4):
                 assert np.abs(Q).max() < 2 ** 31 and ((Q & 127) <= 126).all()
             field = Q & 127
             assert (field & 1 == 0).all()
-            bits = (field.astype(np.uint64) << np.uint64(25)) | (bits >> np.uint64(7))           # v_alignbit_b32 bits, Q, bits, 7
-            Q = (Q & ~127) | 63                                                                # v_and_or_b32
-        bits >>= np.uint64(7 * (4 - ng))                    # group gi of the word: field at bit 4 + 7 gi, its tags at 5 + 7 gi
-        dec[w, coordA] = bits
+            bits |= (Q & 255).astype(np.uint64) << np.uint64(8 * gi)       # ds_write_b8: byte gi of the lane's decision word (bit 7: metric)
+            Q = (Q & ~127) | 63                                            # v_and_or_b32
+        dec[w, coordA] = bits                               # group gi of the word: its tags at bits 1 + 8 gi .. 6 + 8 gi
     out = np.zeros(nsteps, dtype=np.uint8)
     A = 0
     for w in range(nwords - 1, -1, -1):
         ng = min(4, G - 4 * w)
         for gi in range(ng - 1, -1, -1):
-            h = (int(dec[w, A]) >> (5 + 7 * gi)) & 63
+            h = (int(dec[w, A]) >> (1 + 8 * gi)) & 63
             for q in range(6):
                 out[(4 * w + gi) * 6 + q] = (A >> q) & 1
             A ^= (~h) & 63
