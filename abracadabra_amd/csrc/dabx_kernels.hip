@@ -759,10 +759,12 @@ __device__ __forceinline__ uint32_t soft_tab_entry(const VitSrc &src, uint32_t k
     return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(k, (uint32_t)TI_SEG) + wrap;
 }
 
-// depuncturing word of trellis step tau (0 = past the end)
-__device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info, int tau, int nsteps)
+// depuncturing word of trellis step tau; the table ends with a zero word (dabx_spec.hpp: step_info), which the steps past the
+// end read: no branch, and a scalar base + 32-bit offset as the address
+__device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info, uint32_t tau, uint32_t nsteps)
 {
-    return tau < nsteps ? info[tau] : 0u;
+    const uint32_t off = (tau < nsteps ? tau : nsteps) * 4u;
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(info) + off);
 }
 // The soft values of the step described by w as the A row the matrix core wants: (2 (x0 + x3), 2 x1, 2 x2, tag), one byte
 // each, zero where punctured.  x0 and x3 belong to the same generator polynomial and |x| <= 31, so twice their sum fits a
@@ -952,13 +954,15 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     if (lane < 19) xs[64 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
     int xa = gather_step(src, tab, sh, step_word(info, tl, nsteps), tag);
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
+    uint32_t tau_fetch = 2 * VIT_BLK + (uint32_t)tl;             // the step whose depuncturing word this lane loads next
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
         xs[lane] = xa;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
                                                                  // operations execute in order, the previous block's reads are done
 #ifndef DABX_PROBE_NOGATHER
         xa = gather_step(src, tab, sh, wnext, tag);
-        wnext = step_word(info, (blk + 2) * VIT_BLK + tl, nsteps);
+        wnext = step_word(info, tau_fetch, nsteps);
+        tau_fetch += VIT_BLK;
 #endif
         const uint32_t va = va0;
         uint32_t bits = 0;

@@ -212,7 +212,7 @@ inline bool any_profile(int option, int level, int kbps, Profile &p)
 inline std::vector<uint32_t> step_info(const Profile &p)
 {
     std::vector<uint32_t> info;
-    info.reserve(p.steps());
+    info.reserve(p.steps() + 1);
     uint32_t off = 0;
     auto emit = [&](int ones) {
         info.push_back((off << 5) | static_cast<uint32_t>(8 * (4 - ones)));
@@ -222,6 +222,7 @@ inline std::vector<uint32_t> step_info(const Profile &p)
         for (int blk = 0; blk < p.L[s]; ++blk)
             for (int g = 0; g < 32; ++g) emit(punct_group_ones(p.PI[s], g & 7));
     for (int g = 0; g < 6; ++g) emit(2);
+    info.push_back(0);                       // word [steps()]: what k_viterbi's fetch reads for a step past the end (nothing to load)
     return info;
 }
 
