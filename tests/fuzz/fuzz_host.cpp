@@ -1,4 +1,4 @@
-// Sanitizer harness for the host-side parsers (FIG database, PAD, packet mode, raw-file probe, TII detector):
+// Sanitizer harness for the host-side parsers (FIG database, PAD, packet mode incl. its FEC frames, raw-file probe, TII detector):
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -I../../abracadabra_amd/csrc -o fuzz_host fuzz_host.cpp && ./fuzz_host
 // Feeds random and mutated-valid input; any out-of-bounds access or UB aborts.  CPU only (no HIP involved).
 #include <cstdint>
@@ -85,6 +85,36 @@ int main()
                 }
             dec.feed_frame(f.data(), fb);
             ++pkts;
+        }
+    }
+    // ---- packet mode with FEC frames: the decoder locks on runs of FEC packets (address 1022, counters 0..8), fills tables by
+    // position and runs RS(204,188) over garbage rows; the switch is flipped at random, the structure broken at random
+    for (int round = 0; round < 300; ++round) {
+        packet::Decoder dec;
+        dec.address = rnd(2) ? -1 : rnd(1024);
+        dec.set_fec(rnd(4) != 0);
+        long sink = 0;
+        dec.on_data_group = [&](int, const uint8_t *d, int n) { for (int i = 0; i < n; ++i) sink += d[i]; };
+        int unit = rnd(103);
+        for (int k = 0; k < 60; ++k) {
+            const int fb = 24 * (1 + rnd(24));
+            std::vector<uint8_t> f(static_cast<size_t>(fb));
+            for (auto &b : f) b = static_cast<uint8_t>(rnd(8) ? 0 : rng());             // mostly zeros: few RS errors, sometimes too many
+            for (int pos = 0; pos + 24 <= fb; pos += 24, unit = (unit + 1) % 103)
+                if (unit >= 94 && rnd(20)) {                                             // FEC packets where the frame structure puts them
+                    f[static_cast<size_t>(pos)] = static_cast<uint8_t>(((unit - 94) << 2) | 3);
+                    f[static_cast<size_t>(pos + 1)] = 0xFE;
+                }
+            if (rnd(50) == 0) unit = rnd(103);                                           // the structure slips
+            if (rnd(40) == 0) dec.set_fec(rnd(2));
+            dec.feed_frame(f.data(), fb);
+            ++pkts;
+        }
+        std::vector<uint8_t> cw(204);
+        for (int t = 0; t < 20; ++t) {                                                   // the RS decoder on its own: 0..12 errors in a zero word
+            std::fill(cw.begin(), cw.end(), 0);
+            for (int e = rnd(13); e > 0; --e) cw[static_cast<size_t>(rnd(204))] = static_cast<uint8_t>(rng());
+            sink += packet::rs::decode(cw.data(), 204);
         }
     }
     // ---- raw-file probe and TII detector
