@@ -51,8 +51,8 @@ VALU_CYCLES_PER_WAVE_INST = 2                           # wave64 on a SIMD-32 (M
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=15)       # the GPU reaches its steady clocks after about ten steps (30 ms)
     ap.add_argument("--streams", type=int, default=256, help="ensembles per GPU")
     ap.add_argument("--frames", type=int, default=8, help="transmission frames per stream per step")
     ap.add_argument("--period", type=int, default=12, help="period of the synthetic signal in frames (multiple of 4)")

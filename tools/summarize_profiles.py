@@ -18,13 +18,22 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag, streams=256, frames=8):
+def main(tag, streams=256, frames=8, timed=40):
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     ks = glob.glob(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     out = {"kernel_stats": list(csv.DictReader(open(ks))), "pmc": {}}
+    # the same run, timed region only: the average over each kernel's LAST `timed` launches (bench.py's K timed steps follow its
+    # W warm-up steps, during which the GPU still ramps its clocks; the *_kernel_stats.csv average includes those)
+    kt = glob.glob(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_trace.csv"))
+    if kt:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(kt[0])):
+            per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        out["timed_region"] = {"launches": timed, "average_ns": {k: round(sum(d for _, d in sorted(v)[-timed:]) / len(sorted(v)[-timed:]), 1)
+                                                               for k, v in per.items() if k.startswith(("k_", "void k_"))}}
     for part in ("fetch", "write", "sq", "sq2"):
         f = glob.glob(os.path.join(src, f"prof_{tag}_{part}", "*", "*_counter_collection.csv"))[0]
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
