@@ -39,8 +39,9 @@ def main():
         nom = re.sub(r'\s*"s_waitcnt lgkmcnt\([0-5]\)\\n\\t" \\\n\s*"v_mfma[^"]*" \\\n', '\n', nom)
         nom = re.sub(r'\s*"s_nop 7\\n\\t" \\\n\s*"s_nop 3\\n\\t" \\\n', '\n', nom)
         build("libP1_no_mfma.so", nom)
-        noge = re.sub(r'\s*"v_alignbit_b32 [^"]*" \\\n', '\n', src)
-        noge = re.sub(r'"v_and_b32 %\[pm\], -64, %\[pm\]', '"s_nop 0', noge)
+        noge = re.sub(r'\s*"ds_write_b8 [^"]*" \\\n', '\n', src)
+        noge = re.sub(r'"v_and_or_b32 %\[pm\], %\[pm\], %\[m128\], 63', '"s_nop 0', noge)
+        assert noge != src
         build("libP2_no_group_end.so", noge)
         build("libP3_no_gather.so", src, "-DDABX_PROBE_NOGATHER")
         build("libP4_no_merge_no_traceback.so", src, "-DDABX_PROBE_NOTRACE")
