@@ -526,6 +526,21 @@ void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
     }
 }
 
+// Dynamic range control of MPEG Layer II audio (EN 300 401 §7.4.1): the F-PAD — the last two bytes of an audio frame — of
+// type 00 with byte L indicator 0001 carries six bits of DRC data in byte L, a gain in steps of 0.25 dB for the FOLLOWING
+// frame.  The reference hands it to the host as header.mp2DRC (dabsdr.h:47-60), which applies it to the next decoded frame
+// (src/audiodecoder.cpp:285-294, 326).  `second_half`: this logical frame completes a 24 kHz (LSF) audio frame.
+uint8_t mp2_drc(bool second_half, const uint8_t *frame, int len)
+{
+    if (len < 4) return 0;
+    if (!second_half) {
+        if (frame[0] != 0xFF || (frame[1] & 0xF0) != 0xF0) return 0;   // not the start of an audio frame
+        if (!((frame[1] >> 3) & 1)) return 0;                          // LSF: the F-PAD comes with the second logical frame
+    }
+    const uint8_t f0 = frame[len - 2], f1 = frame[len - 1];
+    return ((f0 >> 6) == 0 && (f0 & 0x0F) == 1) ? static_cast<uint8_t>(f1 >> 2) : 0;
+}
+
 // MPEG Layer II audio frames: 48 kHz frames are one logical frame long, 24 kHz (LSF) frames two; the second half
 // of an LSF frame does not start with a sync word
 void feed_mp2_pad(Selection *sp, const uint8_t *frame, int len)
@@ -725,6 +740,7 @@ void after_step(dabsdr_s *h)
                     }
                     dabsdrAudioCBData_t d;
                     d.id = sp->id; d.ASCTy = static_cast<uint8_t>(sp->ascty); d.header.raw = 0;
+                    if (sp->ascty == 0) d.header.mp2DRC = mp2_drc(!sp->mp2_half.empty(), frame, static_cast<int>(fb));
                     d.auLen = static_cast<uint16_t>(fb); d.pAuData = frame;
                     if (sp->id == DABSDR_ID_AUDIO_PRIMARY) h->audio_bytes_acc += d.auLen;
                     if (h->audio_cb) h->audio_cb(&d, h->audio_ctx);
@@ -990,6 +1006,18 @@ DABSDR_API int dabsdr_amd_pad_decode_mp2(const uint8_t *frames, int n_bytes, uin
     }
     if (stats) { stats[0] = dec.stats.pads; stats[1] = dec.stats.dl_ok; stats[2] = dec.stats.dl_crc_err; stats[3] = dec.stats.dg_ok; stats[4] = dec.stats.dg_crc_err; }
     return overflow ? -1 : used;
+}
+
+// test hook (CPU only): header.mp2DRC for each of n logical frames of frame_bytes (MPEG Layer II sub-channel), as after_step() sets it
+DABSDR_API int dabsdr_amd_mp2_drc(const uint8_t *frames, int n_frames, int frame_bytes, uint8_t *out)
+{
+    Selection sel;
+    for (int i = 0; i < n_frames; ++i) {
+        const uint8_t *f = frames + static_cast<size_t>(i) * frame_bytes;
+        out[i] = mp2_drc(!sel.mp2_half.empty(), f, frame_bytes);
+        feed_mp2_pad(&sel, f, frame_bytes);
+    }
+    return n_frames;
 }
 
 // test hook (CPU only): logical frames of a packet-mode sub-channel (n_frames x frame_bytes) -> data groups as records

@@ -179,3 +179,31 @@ def test_dynamic_label_from_mpeg_layer2_frames():
         recs, st = decode_mp2(frames)
         assert recs == [g[:-2] for g in groups], (kbps, mono, lsf)
         assert b"".join(r[2:] for r in recs).decode("latin-1") == text
+
+
+def test_mp2_drc_comes_from_the_fpad_of_the_audio_frame():
+    """EN 300 401 §7.4.1: F-PAD type 00 with byte L indicator 0001 carries six bits of DRC data (0.25 dB steps) in byte L; the
+    reference passes it on as header.mp2DRC and the host scales the NEXT frame by 10^(DRC / 80) (audiodecoder.cpp:285-294, 326).
+    48 kHz frames: one logical frame each; 24 kHz (LSF) frames: two, the F-PAD ends the second."""
+    L = aa.load_library()
+    L.dabsdr_amd_mp2_drc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+
+    def drc_of(frames, fb):
+        blob = np.frombuffer(b"".join(frames), dtype=np.uint8).copy()
+        n = blob.size // fb
+        out = np.zeros(n, dtype=np.uint8)
+        assert L.dabsdr_amd_mp2_drc(blob.ctypes.data, n, fb, out.ctypes.data) == n
+        return out.tolist()
+
+    def fpad(drc=None, xind=0):
+        return bytes([(xind << 4) | (1 if drc is not None else 0), ((drc or 0) << 2)])
+
+    # 48 kHz, 128 kbit/s: DRC 0, 10 (2.5 dB), none, 63 (15.75 dB), an F-PAD of another type
+    fr = [mp2_frame(128, fpad(0)), mp2_frame(128, fpad(10)), mp2_frame(128, fpad(None)), mp2_frame(128, fpad(63)),
+          mp2_frame(128, bytes([0x80 | 0x01, 40 << 2]))]
+    assert drc_of(fr, 384) == [0, 10, 0, 63, 0]
+    # 24 kHz, 64 kbit/s: the audio frame spans two logical frames of 192 bytes; only its end carries the F-PAD
+    fr = [mp2_frame(64, fpad(7), lsf=True), mp2_frame(64, fpad(None), lsf=True), mp2_frame(64, fpad(33), lsf=True)]
+    assert drc_of(fr, 192) == [0, 7, 0, 0, 0, 33]
+    # a frame that is not the start of an audio frame (lost sync): nothing
+    assert drc_of([bytes(384)], 384) == [0]
