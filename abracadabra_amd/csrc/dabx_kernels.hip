@@ -766,30 +766,28 @@ __device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info,
     const uint32_t off = (tau < nsteps ? tau : nsteps) * 4u;
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(info) + off);
 }
-// The soft values of the step described by w as the A row the matrix core wants: (2 (x0 + x3), 2 x1, 2 x2, tag), one byte
-// each, zero where punctured.  x0 and x3 belong to the same generator polynomial and |x| <= 31, so twice their sum fits a
-// byte.  A step keeps a prefix of its four bits (dabx_spec.hpp: step_info), so the four bytes at the step's offset are
-// loaded unconditionally (issued together, no branch, valid addresses: the buffers carry slack) and the punctured ones
-// are masked off.  tag = (1 << phase of the step) << 24, a constant of the lane that gathers it.
-__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w, uint32_t tag)
+// The soft values of the step described by w as the A row the matrix core wants: (2 x0, 2 x1, 2 x2, 2 x3), one byte each,
+// zero where punctured (|x| <= 31, so twice a value fits its byte).  A step keeps a prefix of its four bits (dabx_spec.hpp:
+// step_info), so the four bytes at the step's offset are loaded unconditionally (issued together, no branch, valid addresses:
+// the buffers carry slack), shifted left by one inside their bytes, and the punctured ones are masked off.
+__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
 {
     const uint32_t i0 = w >> 5;
     const uint32_t *t = tab + (i0 & 15u);
     const uint32_t q = (i0 >> 4) << sh;
     const uint8_t *base = reinterpret_cast<const uint8_t *>(src.base);
     const uint32_t b0 = base[t[0] + q], b1 = base[t[1] + q], b2 = base[t[2] + q], b3 = base[t[3] + q];
-    const uint32_t W = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) & (0xFFFFFFFFu >> (w & 31u));
-    const uint32_t x03 = (W + (W >> 24)) & 0xFFu;                  // byte arithmetic modulo 256: two's complement sum
-    const uint32_t v = x03 | (W & 0x00FFFF00u);
-    // every byte holds a value of -62..62: shifted left by one inside its byte it is twice that value (bit 7 = bit 6 = sign)
-    return (int)(((v << 1) & 0x00FEFEFEu) | tag);
+    const uint32_t W = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    // every byte holds a value of -31..31: shifted left by one inside its byte it is twice that value; 0xFE per kept byte
+    // clears the neighbour's sign bit that came in from below, 0 per punctured byte clears the byte
+    return (int)((W << 1) & (0xFEFEFEFEu >> (w & 31u)));
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
 // Path metrics are scaled by 128; the low seven bits of a lane's value Q are a field that starts every group of six
 // steps at 63 and records the keep(1)/receive(0) history of the lane's SURVIVOR — it travels with the path through the
 // max.  Per step, 3 VALU issues and ONE number from the matrix core, X = 128 M + (1 << ph)
-// (M = +-x0 +-x1 +-x2 +-x3, the branch metric of the lane's state):
+// (M = +-x0 +-x1 +-x2 +-x3, the branch metric of the lane's state; 128 M = (2 x) . (+-64), the tag is the MFMA's C operand):
 //   S = Q - X                     sent to the butterfly partner: the field goes down by 1 << ph
 //   K = Q + X                     kept: the field goes up by 1 << ph
 //   Q' = max(K, S of the butterfly partner lane)
@@ -928,11 +926,11 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         for (int i = 0; i < 6; ++i) st |= lane_coord(lane, (i + ph) % 6) << i;
         int u = st & 1, o = conv_out0(st), kg = 0;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {                      // x3 rides with x0: the same generator polynomial
+        for (int j = 0; j < 4; ++j) {
             int neg = ((o >> (3 - j)) & 1) ^ u;
             kg |= (neg ? 0xC0 : 0x40) << (8 * j);          // -+64
         }
-        sk[ph] = kg | (1 << 24);                           // fourth column: 1 (the step's tag 1 << ph rides in the A row)
+        sk[ph] = kg;                                       // (the step's tag 1 << ph is the C operand of the MFMA)
     }
     const int coordA = lane ^ (((lane >> 2) & 1) * 3);          // coordinates of this lane in the basis XV
     const int lane_x32 = (lane ^ 32) << 2;                       // ds_bpermute address of the xor-32 partner
@@ -949,10 +947,9 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);
     const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 64;
     const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // LDS byte address of the wave's decision ring
-    const uint32_t tag = (1u << (lane % 6)) << 24;               // a block is 48 steps: lane tau gathers a step of phase tau mod 6
     const int sh = src.slot_mask < 0 ? 4 : 0;
     if (lane < 19) xs[64 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
-    int xa = gather_step(src, tab, sh, step_word(info, tl, nsteps), tag);
+    int xa = gather_step(src, tab, sh, step_word(info, tl, nsteps));
     uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
     uint32_t tau_fetch = 2 * VIT_BLK + (uint32_t)tl;             // the step whose depuncturing word this lane loads next
     uint32_t A = 0;
@@ -960,7 +957,7 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
         xs[lane] = xa;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
                                                                  // operations execute in order, the previous block's reads are done
 #ifndef DABX_PROBE_NOGATHER
-        xa = gather_step(src, tab, sh, wnext, tag);
+        xa = gather_step(src, tab, sh, wnext);
         wnext = step_word(info, tau_fetch, nsteps);
         tau_fetch += VIT_BLK;
 #endif

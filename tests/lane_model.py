@@ -45,8 +45,8 @@ def decode(x4):
 
     Mirrors viterbi_wave().  Path metrics are scaled by 128; the low seven bits of a lane's value Q carry a field that
     starts every group of six steps at 63.  One number per step and lane comes from the matrix core: with the soft values
-    packed as (2 (x0 + x3), 2 x1, 2 x2, 1 << ph) — generators 0 and 3 of the DAB mother code are the same polynomial, and
-    twice the sum fits a byte because |x| <= 31 — and the lane's signs as (+-64, +-64, +-64, 1), X = 128 M + (1 << ph).
+    as (2 x0, 2 x1, 2 x2, 2 x3) — twice a value fits a byte because |x| <= 31 —, the lane's signs as (+-64, +-64, +-64, +-64)
+    and the constant 1 << ph as the accumulator input, X = 128 M + (1 << ph).
     The kept candidate is Q + X, the one sent to the butterfly partner Q - X: the field of a survivor goes up by 1 << ph
     where it was kept and down by 1 << ph where it was received, so after the six steps it has gone from 63 to
     2 * (sum of the kept steps' 1 << ph): bits 1..6 are the keep/receive tags of ITS survivor path, they travelled with
@@ -57,7 +57,6 @@ def decode(x4):
     nsteps = len(x4)
     assert nsteps % 6 == 0 and np.abs(x4).max(initial=0) <= 31
     sig = sig_tables()
-    assert np.array_equal(sig[:, :, 0], sig[:, :, 3])                  # x0 and x3: the same generator (133 octal)
     lanes = np.arange(64)
     coordA = lanes ^ (((lanes >> 2) & 1) * 3)
     Q = np.full(64, PM_INIT * 128, dtype=np.int64)
@@ -73,10 +72,10 @@ def decode(x4):
             for ph in range(6):
                 t = (4 * w + gi) * 6 + ph
                 x = x4[t].astype(np.int64)
-                a = np.array([2 * (x[0] + x[3]), 2 * x[1], 2 * x[2], 1 << ph])                 # MFMA A row (int8 each)
+                a = 2 * x                                                   # MFMA A row (int8 each): twice the four soft values
                 assert np.abs(a).max() <= 127
-                b = np.concatenate([64 * sig[ph][:, :3], np.ones((64, 1), dtype=np.int64)], axis=1)   # MFMA B column of every lane
-                X = b @ a
+                b = 64 * sig[ph]                                            # MFMA B column of every lane: its four branch signs
+                X = b @ a + (1 << ph)                                       # C operand: the tag, an inline constant
                 keep = Q + X
                 send = Q - X
                 recv = send[lanes ^ XV[ph]]
