@@ -86,7 +86,27 @@ class LegacyHost:
             with self.lock:
                 self.data_groups.append((d.id, d.SCId, d.userAppType, bytes(np.ctypeslib.as_array(d.pDgData, shape=(d.dgLen,)))))
 
-        self._keep = (get_samples, on_ntf, on_dg)
+        class AudioCB(C.Structure):                   # dabsdrAudioCBData_t (dabsdr.h:71-78)
+            _fields_ = [("id", C.c_int), ("ASCTy", C.c_uint8), ("header", C.c_uint8), ("auLen", C.c_uint16), ("pAuData", C.POINTER(C.c_uint8))]
+
+        class DlCB(C.Structure):                      # dabsdrDynamicLabelCBData_t (dabsdr.h:81-86)
+            _fields_ = [("id", C.c_int), ("len", C.c_uint16), ("pData", C.POINTER(C.c_uint8))]
+
+        self.audio, self.labels = [], []
+
+        @C.CFUNCTYPE(None, C.POINTER(AudioCB), C.c_void_p)
+        def on_audio(p, ctx):
+            a = p.contents
+            with self.lock:
+                self.audio.append((a.id, a.ASCTy, a.header, bytes(np.ctypeslib.as_array(a.pAuData, shape=(a.auLen,)))))
+
+        @C.CFUNCTYPE(None, C.POINTER(DlCB), C.c_void_p)
+        def on_dl(p, ctx):
+            d = p.contents
+            with self.lock:
+                self.labels.append(bytes(np.ctypeslib.as_array(d.pData, shape=(d.len,))))
+
+        self._keep = (get_samples, on_ntf, on_dg, on_audio, on_dl)
         L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
         assert L.dabsdrInit(C.byref(self.handle)) == 0
         for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
@@ -96,6 +116,9 @@ class LegacyHost:
         L.dabsdrRegisterNotificationCb(self.handle, C.cast(on_ntf, C.c_void_p), None)
         L.dabsdrRegisterDataGroupCb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabsdrRegisterDataGroupCb(self.handle, C.cast(on_dg, C.c_void_p), None)
+        for name, fn in (("dabsdrRegisterAudioCb", on_audio), ("dabsdrRegisterDynamicLabelCb", on_dl)):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            getattr(L, name)(self.handle, C.cast(fn, C.c_void_p), None)
         for name in ("dabsdr", "dabsdrRequest_GetEnsemble", "dabsdrRequest_GetServiceList", "dabsdrRequest_Exit"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.dabsdrRequest_Tune.argtypes = [C.c_void_p, C.c_uint32]

@@ -139,6 +139,55 @@ def test_packet_mode_fec_frames_are_corrected_once_fig_0_14_announces_them():
         host.close()
 
 
+def test_mpeg_layer2_service_frames_drc_and_dynamic_label():
+    """a DAB (MPEG Layer II) audio service on a UEP sub-channel: the audio callback gets every logical frame as it was sent
+    (ASCTy 0, dabsdr.h:71-78) with header.mp2DRC = the DRC data of the frame's F-PAD, and the X-PAD's dynamic label arrives
+    through the label callback (src/radiocontrol.cpp:2542, src/audiodecoder.cpp:326)."""
+    from legacy_host import NID, LegacyHost
+    from tests.test_pad import dl_groups, mp2_frame, spread, xpad_var
+    sub = [[0, 2, 35, 0]]                                             # UEP table index 35: 128 kbit/s, 96 CU -> ASCTy 0 in FIG 0/2
+    sid, n_frames = 0x1A01, 30
+    text = "Layer II over the GPU: DRC and DLS"
+    rows = []
+    for rep in range(40):                                             # more than the 120 logical frames of the signal
+        for g in dl_groups(text, toggle=rep & 1):
+            for part in spread(g, 2, 12):
+                pad = bytearray(xpad_var([part]))
+                drc = len(rows) % 64
+                pad[-2] |= 0x01                                       # byte L indicator 0001: byte L carries DRC data ...
+                pad[-1] |= drc << 2                                   # ... in its upper six bits (the CI flag stays in bit 1)
+                rows.append((mp2_frame(128, bytes(pad)), drc))
+    rows = rows[:n_frames * 4]
+    payload = np.zeros((n_frames * 4, 384), dtype=np.uint8)
+    for i, (f, _) in enumerate(rows):
+        payload[i] = np.frombuffer(f, dtype=np.uint8)
+    iq, _, _ = ob.tx_generate(seed=99, eid=0x1237, n_frames=n_frames, subch=sub, delay=1800, snr_db=24.0, cfo_hz=-250.0, payload=payload)
+    host = LegacyHost(iq.astype(np.float32) - 128.0, gate_at=8 * 196608)
+    try:
+        host.tune()
+        host.wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)
+        time.sleep(0.5)
+        host.L.dabsdrRequest_GetServiceComponents(host.handle, sid)
+        comps = host.wait_for(lambda e: e["nid"] == NID["SERVICE_COMPONENT_LIST"] and e["status"] == 0)[-1]["comps"]
+        assert comps[0]["tmid"] == 0 and comps[0]["ascty"] == 0 and comps[0]["kbps"] == 128
+        host.L.dabsdrRequest_ServiceSelection(host.handle, sid, 0, 0)
+        assert host.wait_for(lambda e: e["nid"] == NID_SERVICE_SELECTION)[-1]["status"] == 0
+        host.open_gate()
+        host.wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e["at"] >= (n_frames - 2) * 196608, timeout=60)
+        with host.lock:
+            audio, labels = list(host.audio), list(host.labels)
+        sent = [f for f, _ in rows]
+        good = [a for a in audio if a[3] in sent]                     # (the zeros after the end of the signal decode to something else)
+        assert len(good) >= 40 and all(a[0] == 0 and a[1] == 0 for a in good)
+        first = sent.index(good[0][3])
+        assert [a[3] for a in good] == sent[first:first + len(good)]                          # every logical frame, in order
+        assert [a[2] for a in good] == [rows[first + i][1] for i in range(len(good))]          # header.mp2DRC
+        msg = b"".join(sg[2:2 + (sg[0] & 0x0F) + 1] for sg in labels)
+        assert text.encode("latin-1") in msg
+    finally:
+        host.close()
+
+
 def test_deinit_while_the_input_callback_blocks():
     """the host's getSamples waits on a condition variable until samples arrive (inputdevice.cpp:70-85); Deinit must not
     hang on it (the reference cancels its thread)"""
