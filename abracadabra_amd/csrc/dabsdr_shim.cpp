@@ -92,6 +92,7 @@ struct dabsdr_s {
     std::vector<float> first_frame;      // input held back until one whole frame has been seen (the gain is fixed on it)
     int16_t *frame_s16 = nullptr;        // the frame being collected for the GPU: page-locked, so its copy needs no synchronisation
     float frame_peak = 0.0f;             // |sample| peak of the frame in progress (gain hysteresis)
+    int frame_shift = 0;                 // the gain (power of two) the frame in progress is converted with
     int frame_fill = 0;
     int msc_stride = 0;                  // bytes per CIF of the running selections, as the GPU context has them
     std::atomic<bool> worker_done{false};
@@ -504,6 +505,7 @@ void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
     // plain float arithmetic the compiler vectorises: x * g is exact (power of two), adding and subtracting 1.5 * 2^23
     // rounds to the nearest integer, ties to even (|x * g| < 2^22 after the clamp), like std::nearbyint but without a call
     const float g = std::ldexp(1.0f, h->gain_shift);
+    if (h->frame_fill == 0) h->frame_shift = h->gain_shift;
     float pk[16];                                                       // sixteen independent running maxima: no serial dependency
     for (int j = 0; j < 16; ++j) pk[j] = h->frame_peak;
     for (int i = 0; i + 16 <= n_values; i += 16)                        // n_values is a multiple of 16 (chunks of 16384 samples)
@@ -672,12 +674,19 @@ void after_step(dabsdr_s *h)
         notify(h, DABSDR_NID_SYNC_STATUS, DABSDR_NSTAT_SUCCESS, &s, sizeof s);
     }
     h->fib_err_acc += static_cast<uint32_t>(12 - good);
+    // spectra are powers of the HOST's samples (the reference: un-normalised |FFT|^2 of what the input callback delivered,
+    // signalbackend.cpp:203 subtracts the FFT gain only): the adapter's power-of-two gain is taken out again
+    const float inv_g2 = std::ldexp(1.0f, -2 * h->frame_shift);
     if (h->spectrum_on && h->spec_cb) {
         h->spectrum.resize(2048);
-        if (dabx_get_spectrum(h->ctx, 0, h->spectrum.data()) == DABX_OK) h->spec_cb(h->spectrum.data(), DABSDR_SPECT_SIGNAL, h->spec_ctx);
+        if (dabx_get_spectrum(h->ctx, 0, h->spectrum.data()) == DABX_OK) {
+            if (h->frame_shift) for (float &v : h->spectrum) v *= inv_g2;
+            h->spec_cb(h->spectrum.data(), DABSDR_SPECT_SIGNAL, h->spec_ctx);
+        }
     }
     if ((h->tii_on || h->spectrum_on) && st.locked) {
         if (have_null) {
+            if (h->frame_shift) for (float &v : h->null_power) v *= inv_g2;
             if (h->spectrum_on && h->spec_cb) h->spec_cb(h->null_power.data(), DABSDR_SPECT_NULL, h->spec_ctx);
             if (h->tii_on) {
                 const auto ids = tii::detect(h->null_power.data(), h->tii_mode == DABSDR_TII_MODE_CONSERVATIVE ? 8.0f : 4.0f);

@@ -106,7 +106,14 @@ class LegacyHost:
             with self.lock:
                 self.labels.append(bytes(np.ctypeslib.as_array(d.pData, shape=(d.len,))))
 
-        self._keep = (get_samples, on_ntf, on_dg, on_audio, on_dl)
+        self.spectra = []
+
+        @C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_void_p)
+        def on_spectrum(p, kind, ctx):                # dabsdrSpectrumCBFunc_t: 2048 floats, borrowed (dabsdr.h:393)
+            with self.lock:
+                self.spectra.append((kind, np.ctypeslib.as_array(p, shape=(2048,)).copy()))
+
+        self._keep = (get_samples, on_ntf, on_dg, on_audio, on_dl, on_spectrum)
         L.dabsdrInit.argtypes = [C.POINTER(C.c_void_p)]
         assert L.dabsdrInit(C.byref(self.handle)) == 0
         for name in ("dabsdrRegisterInputFcn", "dabsdrRegisterDummyInputFcn"):
@@ -116,7 +123,7 @@ class LegacyHost:
         L.dabsdrRegisterNotificationCb(self.handle, C.cast(on_ntf, C.c_void_p), None)
         L.dabsdrRegisterDataGroupCb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabsdrRegisterDataGroupCb(self.handle, C.cast(on_dg, C.c_void_p), None)
-        for name, fn in (("dabsdrRegisterAudioCb", on_audio), ("dabsdrRegisterDynamicLabelCb", on_dl)):
+        for name, fn in (("dabsdrRegisterAudioCb", on_audio), ("dabsdrRegisterDynamicLabelCb", on_dl), ("dabsdrRegisterSignalSpectrumCb", on_spectrum)):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
             getattr(L, name)(self.handle, C.cast(fn, C.c_void_p), None)
         for name in ("dabsdr", "dabsdrRequest_GetEnsemble", "dabsdrRequest_GetServiceList", "dabsdrRequest_Exit"):

@@ -205,3 +205,36 @@ def test_gpu_noise_input_tune_and_idle_sequences():
         assert host.pos == p                                          # idle
     finally:
         host.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1.0, 1.0 / 128.0, 256.0])
+def test_gpu_signal_spectrum_is_the_power_of_the_hosts_samples(scale):
+    """the spectrum callback delivers 2048 floats of linear power of an UN-NORMALISED 2048-point FFT in natural bin
+    order (index 0 = DC, then +1 .. +1023, -1024 .. -1), from which the host subtracts 66.2 dB of FFT gain
+    (signalbackend.cpp:203-204, 407-429).  So the sum over the bins is 2048 x the energy of the 2048 input samples (Parseval) —
+    of the floats the input callback delivered, whatever gain the adapter applied on the way to its 16-bit ring."""
+    from legacy_host import NID, LegacyHost
+    sub = [[0, 0, 3, 64]]
+    iq, _, _ = ob.tx_generate(seed=131, eid=0x1234, n_frames=14, subch=sub, delay=2000, snr_db=25.0, cfo_hz=700.0)
+    x = (iq.astype(np.float32) - 128.0) * np.float32(scale)
+    host = LegacyHost(x, gate_at=11 * 196608)                        # the un-paced library stops inside the signal, not in the zeros behind it
+    host.L.dabsdrRequest_SignalSpectrum.argtypes = [C.c_void_p, C.c_uint8]
+    try:
+        host.L.dabsdrRequest_SignalSpectrum(host.handle, 1)
+        host.tune(periodic=0)
+        host.wait_for(lambda e: e["nid"] == NID["PERIODIC"] and e.get("level") == 3 and e["at"] >= 9 * 196608)
+        time.sleep(0.3)
+        with host.lock:
+            sig = [p for k, p in host.spectra if k == 0]
+            null = [p for k, p in host.spectra if k == 1]
+        assert len(sig) >= 4 and len(null) >= 4
+        p = np.mean(sig[-4:], axis=0)
+        sample_power = float(np.mean(x[0::2][2656:196608].astype(np.float64) ** 2 + x[1::2][2656:196608].astype(np.float64) ** 2))
+        assert abs(p.sum() / (2048.0 * 2048.0 * sample_power) - 1.0) < 0.15          # Parseval, in the host's units
+        band = np.r_[p[1:769], p[2048 - 768:]]
+        gap = p[800:1248]
+        assert band.mean() / gap.mean() > 100.0 and p[0] < 0.1 * band.mean()          # 1536 carriers either side of an empty centre, natural order
+        assert np.mean(null[-4:], axis=0).sum() < 0.02 * p.sum()                      # the null symbol holds noise only
+    finally:
+        host.close()
