@@ -6,8 +6,12 @@
 // are queued from any thread and answered by notifications.  The worker pulls
 // whole transmission frames through the registered input callback
 // (reference contract: src/input/inputdevice.cpp:70-108 — blocking, fills the
-// buffer completely, zeros when flushed), rounds them to s16 and pushes them into
-// the GPU ring, so the reference's raw-file input drops in unchanged.
+// buffer completely, zeros when flushed) straight into page-locked memory; the
+// GPU turns the floats into the ring's s16 (dabx_push_resampled_from), so the
+// reference's raw-file input drops in unchanged and the host never touches a
+// sample.  When the callback returns faster than real time (a file read as fast
+// as it goes, SURVEY.md §8b "un-paced") up to kMaxBatch frames are decoded per
+// step, and the step runs while the callback fills the next buffer.
 #include "../../include/dabsdr_amd.h"
 #include "../../include/dabx.h"
 #include "fig_db.hpp"
@@ -44,6 +48,36 @@ struct Request {
 };
 
 constexpr int kPullChunk = 16384;        // complex samples per input-callback call (uint16_t length)
+constexpr int kMaxBatch = 8;             // frames per decode step at most (input not paced)
+constexpr int kRingFrames = 32;          // device ring: the step in flight, the one being filled, one frame of history, slack
+
+// what one selected sub-channel contributed to a decode step, identified by the selection's serial number: a selection
+// made or dropped while the step was in flight must not be served from bytes that were laid out for another list
+struct SubSnap {
+    uint64_t serial = 0;
+    int kbps = 0;
+    size_t off = 0;                       // byte offset inside a CIF record
+    bool dabplus = false;
+    std::vector<dabx_superframe_t> recs;  // DAB+: the super frames the step completed ...
+    std::vector<uint8_t> data;            // ... and their RS-corrected bytes
+    uint32_t frames_seen = 0;             // valid logical frames of the sub-channel so far, the step's included
+};
+
+// everything the worker needs from one decode step, fetched before the next step is submitted
+struct StepResults {
+    int n_frames = 0;
+    std::vector<uint8_t> fib, ok;
+    std::vector<dabx_sync_rec_t> rec;
+    dabx_stream_state_t st = {};
+    bool have_null = false, have_spec = false;
+    std::vector<float> spectrum, null_power;      // of the step's last frame
+    int shift = 0;                                // the samples were scaled by 2^shift
+    int32_t peak = 0;                             // their largest |I|, |Q| after scaling
+    size_t stride = 0;
+    bool have_msc = false;
+    std::vector<uint8_t> msc, valid;
+    std::vector<SubSnap> subs;
+};
 
 }  // namespace
 
@@ -64,7 +98,7 @@ struct Selection {
     packet::Decoder pkt;                  // packet mode -> data groups
     std::set<int> xpad_on;                // X-PAD application types the host started (dabsdrRequest_XPadAppStart)
     std::vector<uint8_t> mp2_half;        // first half of a 24 kHz Layer II frame
-    uint32_t sf_stats[6] = {0};           // k_superframe totals of this sub-channel
+    uint64_t serial = 0;                  // unique per selection (StepResults refer to it)
 };
 
 struct dabsdr_s {
@@ -89,11 +123,20 @@ struct dabsdr_s {
     bool gain_set = false;
     bool locked_hint = false;            // the last step left the receiver locked: whole frames are collected; while it is not, every chunk is
                                          // handed on at once, so that the lock comes as early as the samples allow (2.1 frames, not 3)
-    std::vector<float> first_frame;      // input held back until one whole frame has been seen (the gain is fixed on it)
-    int16_t *frame_s16 = nullptr;        // the frame being collected for the GPU: page-locked, so its copy needs no synchronisation
-    float frame_peak = 0.0f;             // |sample| peak of the frame in progress (gain hysteresis)
-    int frame_shift = 0;                 // the gain (power of two) the frame in progress is converted with
-    int frame_fill = 0;
+    float *fbuf[2] = {nullptr, nullptr}; // page-locked: kMaxBatch frames of float IQ each, filled by the input callback, read by the GPU
+    bool buf_busy[2] = {false, false};   // a copy out of the buffer may still be in flight
+    int cur = 0, fill = 0;               // buffer being filled / complex samples in it
+    bool inflight = false;               // a decode step has been submitted and not waited for
+    int inflight_frames = 0, inflight_shift = 0;
+    std::vector<SubSnap> inflight_subs;
+    std::deque<StepResults> done;        // fetched, not yet turned into callbacks
+    double pull_s = 0.096;               // running estimate of the time the input callback takes per frame
+    int batch = 1;                       // frames per step: what arrives within 48 ms, at most kMaxBatch
+    int prev_bad = 0;                    // frames in a row without a phase reference symbol at the end of the last delivered step
+    bool pipelined = false;              // the step runs while the next buffer is filled (input faster than ~10 x real time)
+    uint64_t next_serial = 1;
+    int64_t pushed = 0;                  // samples handed to the context since it was created
+    std::deque<std::pair<int64_t, int>> gain_epochs;   // (first sample, gain shift): where the gain changed, for the spectra's units
     int msc_stride = 0;                  // bytes per CIF of the running selections, as the GPU context has them
     std::atomic<bool> worker_done{false};
     dabsdrSyncLevel_t sync_level = DABSDR_SYNC_LEVEL_NO_SYNC;
@@ -102,8 +145,8 @@ struct dabsdr_s {
     uint32_t fib_err_acc = 0;
     figdb::Database db;
     std::vector<std::unique_ptr<Selection>> sel;   // running decoders: primary / secondary audio, data components
-    uint32_t last_sf_stats[6] = {0};      // primary audio's k_superframe totals at the last periodic notification
-    std::vector<uint8_t> sf_data;
+    uint32_t per_sf = 0, per_au_ok = 0, per_au_bad = 0, per_rs_corr = 0, per_rs_fail = 0;   // primary audio since the last periodic notification
+    int per_kbps = 0;
     uint32_t audio_bytes_acc = 0;
     std::vector<figdb::UserApp> app_snapshot;
     bool spectrum_on = false, tii_on = false;
@@ -113,8 +156,6 @@ struct dabsdr_s {
     std::vector<figdb::Service> list_snapshot;       // for the list getters (valid during a callback)
     std::vector<figdb::Component> comp_snapshot;
     uint32_t comp_sid = 0;
-    std::vector<float> fbuf;
-    std::vector<int16_t> sbuf;
 };
 
 namespace {
@@ -220,10 +261,13 @@ void reset_receiver(dabsdr_s *h, dabsdrNtfResetFlags_t flag)
     notify(h, DABSDR_NID_RESET, DABSDR_NSTAT_SUCCESS, &flag, 0);
 }
 
+void drain(dabsdr_s *h);
+
 // (re)program the GPU context with the sub-channels of all running selections, in the order of h->sel
 bool apply_selections(dabsdr_s *h)
 {
     if (!h->ctx) return false;
+    drain(h);                                              // the context takes a new layout only between steps
     std::vector<dabx_subch_t> subs;
     uint64_t dabplus = 0;
     for (size_t k = 0; k < h->sel.size(); ++k) {
@@ -290,12 +334,14 @@ void handle_request(dabsdr_s *h, const Request &r)
             notify(h, DABSDR_NID_TUNE, DABSDR_NSTAT_SUCCESS, &f, 0);
         } else {
             h->frequency = r.a;
-            h->gain_set = false; h->locked_hint = false;
-            h->first_frame.clear();
+            h->gain_set = false; h->locked_hint = false; h->prev_bad = 0;
+            h->fill = 0; h->inflight = false; h->done.clear();
+            h->pushed = 0; h->gain_epochs.clear();
+            h->buf_busy[0] = h->buf_busy[1] = false;       // dabx_destroy drains the copy stream
             h->msc_stride = 0;
             // a fresh context state: drop everything buffered so far
             if (h->ctx) {
-                dabx_config_t cfg = {1, DABX_FMT_S16, 8LL * DABX_FRAME_SAMPLES, 1, 0};
+                dabx_config_t cfg = {1, DABX_FMT_S16, static_cast<int64_t>(kRingFrames) * DABX_FRAME_SAMPLES, kMaxBatch, 0};
                 dabx_destroy(h->ctx);
                 h->ctx = nullptr;
                 if (dabx_create(&cfg, &h->ctx) != DABX_OK) h->ctx = nullptr;
@@ -396,6 +442,7 @@ void handle_request(dabsdr_s *h, const Request &r)
                 if (it == h->db.subch.end()) { st = DABSDR_NSTAT_SERVICE_NOT_READY; break; }
                 auto sp = std::make_unique<Selection>();
                 sp->sid = r.a; sp->scids = static_cast<int>(r.b); sp->id = static_cast<dabsdrDecoderId_t>(r.c);
+                sp->serial = h->next_serial++;
                 sp->packet = pk != nullptr;
                 sp->ascty = pk ? pk->dscty : c.ascty_dscty;
                 sp->kbps = it->second.kbps;
@@ -417,7 +464,7 @@ void handle_request(dabsdr_s *h, const Request &r)
                 h->sel.push_back(std::move(sp));
                 if (apply_selections(h)) {
                     st = DABSDR_NSTAT_SUCCESS;
-                    if (primary) std::memset(h->last_sf_stats, 0, sizeof h->last_sf_stats);
+                    if (primary) h->per_sf = h->per_au_ok = h->per_au_bad = h->per_rs_corr = h->per_rs_fail = 0;
                 } else {                                   // the decoder that was running on this id carries on
                     h->sel.pop_back();
                     for (auto &o : displaced) h->sel.push_back(std::move(o));
@@ -462,11 +509,13 @@ void handle_request(dabsdr_s *h, const Request &r)
         break;
     case Req::SignalSpectrum:
         h->spectrum_on = r.a != 0;
+        drain(h);
         if (h->ctx) dabx_enable_spectrum(h->ctx, (h->spectrum_on ? 1 : 0) | 2);
         break;
     case Req::SetTII:
         h->tii_on = r.a != 0;
         h->tii_mode = r.b;
+        drain(h);
         if (h->ctx) dabx_enable_spectrum(h->ctx, (h->spectrum_on ? 1 : 0) | 2);
         break;
     case Req::InjectFibs:                                   // test hook: FIBs as if the FIC had delivered them
@@ -478,54 +527,29 @@ void handle_request(dabsdr_s *h, const Request &r)
     }
 }
 
-// float IQ from the host -> s16 IQ with a power-of-two gain.  Raw-file input arrives as exact integers
-// (reference: src/input/rawfileinput.cpp:657,692): as long as those fit int16 the gain is 1 and the conversion is
-// lossless.  Anything else (SDR floats in +-1, scaled recordings) gets a gain that puts the peak of the FIRST WHOLE
-// FRAME between 2^12 and 2^13 — headroom of 12 dB upwards, 12 bits downwards — and a slow hysteresis afterwards: a
-// frame that peaks above 30000 halves the gain, one that stays below 256 doubles it.  The receiver normalises every
-// OFDM symbol on its own, so a gain step costs at most the symbol it falls into.
-int choose_shift(const float *in, size_t n_values)
+// float IQ from the host -> s16 IQ with a power-of-two gain, on the GPU (dabx_push_resampled_from: rint(x * 2^shift), clamped).
+// Raw-file input arrives as exact integers (reference: src/input/rawfileinput.cpp:657,692): as long as those fit int16 the
+// gain is 1 and the conversion is lossless.  Anything else (SDR floats in +-1, scaled recordings) gets a gain that puts the
+// peak of the FIRST WHOLE FRAME THAT CARRIES A SIGNAL between 2^12 and 2^13 — headroom of 12 dB upwards, 12 bits downwards —
+// and a slow hysteresis afterwards: a step whose samples peak above 30000 halves the gain, one that stays below 256 doubles
+// it.  The receiver normalises every OFDM symbol on its own, so a gain step costs at most the symbol it falls into.
+// Returns false for a frame without a usable level (all zeros: the host's FIFO hands out zeros while it is flushed,
+// inputdevice.cpp:80-85; or non-finite values): the gain stays open and the next frame decides.
+bool choose_shift(const float *in, size_t n_values, int &shift)
 {
     float mx = 0.0f;
-    bool integral = true;
+    bool integral = true, nan = false;
     for (size_t i = 0; i < n_values; ++i) {
         mx = std::fmax(mx, std::fabs(in[i]));
+        nan = nan || in[i] != in[i];
         integral = integral && in[i] == std::nearbyint(in[i]);
     }
-    if (!(mx > 0.0f) || !std::isfinite(mx)) return 0;
-    if (integral && mx <= 32767.0f && mx >= 16.0f) return 0;           // integer samples that fit: lossless
-    int sh = 0;
-    while (mx * std::ldexp(1.0f, sh) >= 8192.0f) --sh;
-    while (mx * std::ldexp(1.0f, sh) < 4096.0f && sh < 40) ++sh;
-    return sh;
-}
-
-void convert(dabsdr_s *h, const float *in, int16_t *out, int n_values)
-{
-    // plain float arithmetic the compiler vectorises: x * g is exact (power of two), adding and subtracting 1.5 * 2^23
-    // rounds to the nearest integer, ties to even (|x * g| < 2^22 after the clamp), like std::nearbyint but without a call
-    const float g = std::ldexp(1.0f, h->gain_shift);
-    if (h->frame_fill == 0) h->frame_shift = h->gain_shift;
-    float pk[16];                                                       // sixteen independent running maxima: no serial dependency
-    for (int j = 0; j < 16; ++j) pk[j] = h->frame_peak;
-    for (int i = 0; i + 16 <= n_values; i += 16)                        // n_values is a multiple of 16 (chunks of 16384 samples)
-        for (int j = 0; j < 16; ++j) {
-            float v = in[i + j] * g;
-            v = v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v);
-            v = (v + 12582912.0f) - 12582912.0f;
-            const float a = v < 0.0f ? -v : v;
-            pk[j] = a > pk[j] ? a : pk[j];
-            out[i + j] = static_cast<int16_t>(static_cast<int32_t>(v));
-        }
-    float peak = pk[0];
-    for (int j = 1; j < 16; ++j) peak = pk[j] > peak ? pk[j] : peak;
-    h->frame_peak = peak;
-    h->frame_fill += n_values / 2;
-    if (h->frame_fill >= DABX_FRAME_SAMPLES) {                          // once per frame: hysteresis
-        if (peak > 30000.0f) --h->gain_shift;
-        else if (peak < 256.0f && peak > 0.0f && h->gain_shift < 40) ++h->gain_shift;
-        h->frame_fill = 0; h->frame_peak = 0.0f;
-    }
+    if (nan || !(mx > 0.0f) || !std::isfinite(mx)) return false;
+    shift = 0;
+    if (integral && mx <= 32767.0f && mx >= 16.0f) return true;        // integer samples that fit: lossless
+    while (mx * std::ldexp(1.0f, shift) >= 8192.0f) --shift;
+    while (mx * std::ldexp(1.0f, shift) < 4096.0f && shift < 40) ++shift;
+    return true;
 }
 
 // Dynamic range control of MPEG Layer II audio (EN 300 401 §7.4.1): the F-PAD — the last two bytes of an audio frame — of
@@ -635,33 +659,101 @@ bool after_fibs(dabsdr_s *h)
     return true;
 }
 
-void after_step(dabsdr_s *h)
+// Fetch the results of the n_frames-frame step that has just been waited for (the context is idle) into h->done.
+void collect(dabsdr_s *h, int n_frames, int shift, std::vector<SubSnap> subs)
 {
-    uint8_t fib[12 * 32], ok[12];
-    dabx_stream_state_t st;
-    dabx_sync_rec_t rec;
-    if (dabx_get_fib(h->ctx, 0, fib, ok) || dabx_get_state(h->ctx, 0, &st) || dabx_get_sync(h->ctx, 0, &rec)) return;
+    dabx_ctx *c = h->ctx;
+    if (!c || n_frames < 1) return;
+    StepResults r;
+    r.n_frames = n_frames;
+    r.shift = shift;
+    r.fib.resize(static_cast<size_t>(n_frames) * 384);
+    r.ok.resize(static_cast<size_t>(n_frames) * 12);
+    r.rec.resize(static_cast<size_t>(n_frames));
+    if (dabx_get_fib(c, 0, r.fib.data(), r.ok.data()) || dabx_get_state(c, 0, &r.st) || dabx_get_sync(c, 0, r.rec.data())) return;
+    (void)dabx_get_input_peak(c, 0, &r.peak);
+    r.null_power.resize(static_cast<size_t>(n_frames) * 2048);
+    r.have_null = dabx_get_null_spectra(c, 0, r.null_power.data()) == DABX_OK;
+    if (h->spectrum_on && h->spec_cb) {
+        r.spectrum.resize(2048);
+        r.have_spec = dabx_get_spectrum(c, 0, r.spectrum.data()) == DABX_OK;
+    }
+    r.subs = std::move(subs);
+    if (!r.subs.empty()) {
+        for (const auto &sb : r.subs) r.stride += static_cast<size_t>(3 * sb.kbps);
+        // dabx_get_msc copies 4 x the stride the CONTEXT has per frame; it must be the one the records are sliced by
+        if (r.stride == static_cast<size_t>(h->msc_stride)) {
+            r.msc.resize(static_cast<size_t>(n_frames) * 4 * r.stride);
+            r.valid.assign(static_cast<size_t>(n_frames) * 4, 0);
+            r.have_msc = dabx_get_msc(c, 0, r.msc.data(), r.valid.data()) == DABX_OK;
+        }
+        const int max_rec = (4 + 4 * kMaxBatch) / 5;
+        for (size_t k = 0; k < r.subs.size(); ++k) {
+            SubSnap &sb = r.subs[k];
+            if (!sb.dabplus) continue;
+            const size_t s8 = static_cast<size_t>(sb.kbps / 8);
+            sb.recs.resize(max_rec);
+            sb.data.resize(static_cast<size_t>(max_rec) * 110 * s8);
+            const int n = dabx_get_superframes(c, 0, static_cast<int>(k), sb.recs.data(), sb.data.data(), max_rec);
+            sb.recs.resize(n > 0 ? static_cast<size_t>(n) : 0);
+            uint32_t pos[2] = {0, 0};
+            if (n > 0 && dabx_get_superframe_pos(c, 0, static_cast<int>(k), pos) == DABX_OK) sb.frames_seen = pos[0];
+            else sb.recs.clear();
+        }
+    }
+    h->done.push_back(std::move(r));
+}
+
+// wait for the step in flight, if any, and fetch its results
+void drain(dabsdr_s *h)
+{
+    if (!h->inflight) return;
+    h->inflight = false;
+    if (!h->ctx) return;
+    const bool ok = dabx_wait(h->ctx) == DABX_OK;
+    h->buf_busy[0] = h->buf_busy[1] = false;               // the step waited for every copy queued before it
+    if (ok) collect(h, h->inflight_frames, h->inflight_shift, std::move(h->inflight_subs));
+    h->inflight_subs.clear();
+}
+
+// the gain (power of two) the sample with absolute index `pos` was written to the ring with
+int gain_at(const dabsdr_s *h, int64_t pos)
+{
+    int sh = h->gain_epochs.empty() ? h->gain_shift : h->gain_epochs.front().second;
+    for (const auto &e : h->gain_epochs)
+        if (e.first <= pos) sh = e.second;
+    return sh;
+}
+
+Selection *find_selection(dabsdr_s *h, uint64_t serial)
+{
+    for (auto &sp : h->sel)
+        if (sp->serial == serial) return sp.get();
+    return nullptr;
+}
+
+// frame f of a fetched step -> notifications and callbacks, in the order the reference's single-frame loop produces them
+void deliver_frame(dabsdr_s *h, StepResults &r, int f, bool locked)
+{
+    const uint8_t *fib = r.fib.data() + static_cast<size_t>(f) * 384, *ok = r.ok.data() + static_cast<size_t>(f) * 12;
+    const dabx_sync_rec_t &rec = r.rec[static_cast<size_t>(f)];
+    const bool last = f == r.n_frames - 1;
     int good = 0;
     for (int i = 0; i < 12; ++i)
         if (ok[i]) { ++good; h->db.parse_fib(fib + 32 * i); }
-    h->locked_hint = st.locked != 0;
-    const dabsdrSyncLevel_t lvl = !st.locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
+    const dabsdrSyncLevel_t lvl = !locked ? DABSDR_SYNC_LEVEL_NO_SYNC : (good ? DABSDR_SYNC_LEVEL_FIC : DABSDR_SYNC_LEVEL_ON_NULL);
     // SNR: (signal+noise energy of the PRS window - noise energy of the null symbol) / noise energy.
     // The null symbol may carry TII carriers (32 of 1536), so its noise level is taken from the median
     // in-band bin of its spectrum (median of an exponential distribution = mean * ln 2) rather than
     // from its total energy; for a TII-free null the two agree.
-    bool have_null = false;
     double noise = static_cast<double>(rec.e_null);
-    if (st.locked) {
-        h->null_power.resize(2048);
-        have_null = dabx_get_null_spectrum(h->ctx, 0, h->null_power.data()) == DABX_OK;
-        if (have_null) {
-            float band[1536];
-            std::memcpy(band, h->null_power.data() + 1, 768 * sizeof(float));
-            std::memcpy(band + 768, h->null_power.data() + 2048 - 768, 768 * sizeof(float));
-            std::nth_element(band, band + 768, band + 1536);
-            noise = static_cast<double>(band[768]) / 0.6931471805599453;
-        }
+    float *null_power = r.null_power.data() + static_cast<size_t>(f) * 2048;
+    if (r.have_null && locked) {
+        float band[1536];
+        std::memcpy(band, null_power + 1, 768 * sizeof(float));
+        std::memcpy(band + 768, null_power + 2048 - 768, 768 * sizeof(float));
+        std::nth_element(band, band + 768, band + 1536);
+        noise = static_cast<double>(band[768]) / 0.6931471805599453;
     }
     int16_t snr10 = 0;
     const double sig = static_cast<double>(rec.e_sig);
@@ -676,21 +768,22 @@ void after_step(dabsdr_s *h)
     h->fib_err_acc += static_cast<uint32_t>(12 - good);
     // spectra are powers of the HOST's samples (the reference: un-normalised |FFT|^2 of what the input callback delivered,
     // signalbackend.cpp:203 subtracts the FFT gain only): the adapter's power-of-two gain is taken out again
-    const float inv_g2 = std::ldexp(1.0f, -2 * h->frame_shift);
-    if (h->spectrum_on && h->spec_cb) {
-        h->spectrum.resize(2048);
-        if (dabx_get_spectrum(h->ctx, 0, h->spectrum.data()) == DABX_OK) {
-            if (h->frame_shift) for (float &v : h->spectrum) v *= inv_g2;
-            h->spec_cb(h->spectrum.data(), DABSDR_SPECT_SIGNAL, h->spec_ctx);
-        }
+    // (the gain in force where the window was read: gain_at)
+    if (last && r.have_spec && h->spectrum_on && h->spec_cb) {
+        const int sh = gain_at(h, rec.t_sym0);
+        const float inv_g2 = std::ldexp(1.0f, -2 * sh);
+        if (sh) for (float &v : r.spectrum) v *= inv_g2;
+        h->spec_cb(r.spectrum.data(), DABSDR_SPECT_SIGNAL, h->spec_ctx);
     }
-    if ((h->tii_on || h->spectrum_on) && st.locked) {
-        if (have_null) {
-            if (h->frame_shift) for (float &v : h->null_power) v *= inv_g2;
-            if (h->spectrum_on && h->spec_cb) h->spec_cb(h->null_power.data(), DABSDR_SPECT_NULL, h->spec_ctx);
+    {
+        if ((h->tii_on || h->spectrum_on) && locked && r.have_null) {
+            const int sh = gain_at(h, rec.t_sym0 - 2400);
+            const float inv_g2 = std::ldexp(1.0f, -2 * sh);
+            if (sh) for (int i = 0; i < 2048; ++i) null_power[i] *= inv_g2;
+            if (h->spectrum_on && h->spec_cb) h->spec_cb(null_power, DABSDR_SPECT_NULL, h->spec_ctx);
             if (h->tii_on) {
-                const auto ids = tii::detect(h->null_power.data(), h->tii_mode == DABSDR_TII_MODE_CONSERVATIVE ? 8.0f : 4.0f);
-                tii::fold(h->null_power.data(), h->tii_folded);
+                const auto ids = tii::detect(null_power, h->tii_mode == DABSDR_TII_MODE_CONSERVATIVE ? 8.0f : 4.0f);
+                tii::fold(null_power, h->tii_folded);
                 dabsdrNtfTii_t n;
                 std::memset(&n, 0, sizeof n);
                 n.numIds = static_cast<uint8_t>(ids.size());
@@ -705,58 +798,53 @@ void after_step(dabsdr_s *h)
     // (a damaged unit keeps its place with the conceal bit set, as audiodecoder.cpp:183-208 expects), MPEG Layer II
     // sub-channels are handed over one logical frame at a time; their PAD feeds the dynamic label / data group
     // callbacks.  Packet-mode data components: packets -> MSC data groups -> dabsdrDataGroupCBFunc_t.
-    if (!h->sel.empty()) {
-        size_t stride = 0;
-        for (const auto &sp : h->sel) stride += static_cast<size_t>(3 * sp->kbps);
-        // dabx_get_msc copies 4 x the stride the CONTEXT has; it must be the one this loop slices by
-        const bool agree = stride == static_cast<size_t>(h->msc_stride);
-        std::vector<uint8_t> msc(4 * std::max(stride, static_cast<size_t>(h->msc_stride)));
-        uint8_t valid[4] = {0, 0, 0, 0};
-        const bool have_msc = agree && dabx_get_msc(h->ctx, 0, msc.data(), valid) == DABX_OK;
-        size_t off = 0;
-        for (size_t k = 0; k < h->sel.size(); ++k) {
-            Selection *sp = h->sel[k].get();
-            const size_t fb = static_cast<size_t>(3 * sp->kbps);
-            if (!sp->packet && sp->ascty == 63) {
-                const int s8 = sp->kbps / 8;
-                dabx_superframe_t recs[2];
-                h->sf_data.resize(2 * 110 * static_cast<size_t>(s8));
-                const int n = dabx_get_superframes(h->ctx, 0, static_cast<int>(k), recs, h->sf_data.data(), 2);
-                for (int q = 0; q < n; ++q) {
-                    const uint8_t *base = h->sf_data.data() + static_cast<size_t>(q) * 110 * s8;
-                    for (int a = 0; a < recs[q].num_aus; ++a) {
-                        if (!((recs[q].au_valid >> a) & 1)) continue;
-                        dabsdrAudioCBData_t d;
-                        d.id = sp->id; d.ASCTy = 63;
-                        d.header.raw = static_cast<uint8_t>(recs[q].header | (((recs[q].au_ok >> a) & 1) ? 0 : 0x80));
-                        d.auLen = static_cast<uint16_t>(recs[q].au_start[a + 1] - recs[q].au_start[a] - 2);
-                        d.pAuData = base + recs[q].au_start[a];
-                        if (sp->id == DABSDR_ID_AUDIO_PRIMARY) h->audio_bytes_acc += d.auLen;
-                        if (h->audio_cb) h->audio_cb(&d, h->audio_ctx);
-                        if ((recs[q].au_ok >> a) & 1) sp->pad.feed_dabplus_au(d.pAuData, d.auLen);
-                    }
-                }
-                if (n >= 0) dabx_get_superframe_stats(h->ctx, 0, static_cast<int>(k), sp->sf_stats);
-            } else if (have_msc) {
-                for (int c = 0; c < 4; ++c) {
-                    if (!valid[c]) continue;
-                    const uint8_t *frame = msc.data() + static_cast<size_t>(c) * stride + off;
-                    if (sp->packet) {
-                        auto fe = h->db.fec_scheme.find(sp->subch_id);          // FIG 0/14 may arrive after the selection
-                        sp->pkt.set_fec(fe != h->db.fec_scheme.end() && fe->second == 1);
-                        sp->pkt.feed_frame(frame, static_cast<int>(fb));
-                        continue;
-                    }
+    // A super frame belongs to the frame whose CIF completed it: the step's last CIF has index frames_seen - 1.
+    for (SubSnap &sb : r.subs) {
+        Selection *sp = find_selection(h, sb.serial);
+        if (!sp) continue;                                   // stopped or replaced since the step was submitted
+        const size_t fb = static_cast<size_t>(3 * sb.kbps);
+        if (sb.dabplus) {
+            const size_t s8 = static_cast<size_t>(sb.kbps / 8);
+            for (size_t q = 0; q < sb.recs.size(); ++q) {
+                const dabx_superframe_t &sr = sb.recs[q];
+                const int64_t cif = static_cast<int64_t>(sr.first_frame) + 4 - (static_cast<int64_t>(sb.frames_seen) - 4 * r.n_frames);
+                const int64_t fr = cif < 0 ? 0 : cif / 4;
+                if (fr != f) continue;
+                const uint8_t *base = sb.data.data() + q * 110 * s8;
+                const bool primary = sp->id == DABSDR_ID_AUDIO_PRIMARY;
+                if (primary) { ++h->per_sf; h->per_rs_corr += sr.rs_corrected; h->per_rs_fail += sr.rs_failed; h->per_kbps = sb.kbps; }
+                for (int a = 0; a < sr.num_aus; ++a) {
+                    const bool au_ok = (sr.au_ok >> a) & 1;
+                    if (primary) { if (au_ok) ++h->per_au_ok; else ++h->per_au_bad; }
+                    if (!((sr.au_valid >> a) & 1)) continue;
                     dabsdrAudioCBData_t d;
-                    d.id = sp->id; d.ASCTy = static_cast<uint8_t>(sp->ascty); d.header.raw = 0;
-                    if (sp->ascty == 0) d.header.mp2DRC = mp2_drc(!sp->mp2_half.empty(), frame, static_cast<int>(fb));
-                    d.auLen = static_cast<uint16_t>(fb); d.pAuData = frame;
-                    if (sp->id == DABSDR_ID_AUDIO_PRIMARY) h->audio_bytes_acc += d.auLen;
+                    d.id = sp->id; d.ASCTy = 63;
+                    d.header.raw = static_cast<uint8_t>(sr.header | (au_ok ? 0 : 0x80));
+                    d.auLen = static_cast<uint16_t>(sr.au_start[a + 1] - sr.au_start[a] - 2);
+                    d.pAuData = base + sr.au_start[a];
+                    if (primary) h->audio_bytes_acc += d.auLen;
                     if (h->audio_cb) h->audio_cb(&d, h->audio_ctx);
-                    if (sp->ascty == 0) feed_mp2_pad(sp, frame, static_cast<int>(fb));   // MPEG Layer II: PAD at the end of the audio frame
+                    if (au_ok) sp->pad.feed_dabplus_au(d.pAuData, d.auLen);
                 }
             }
-            off += fb;
+        } else if (r.have_msc) {
+            for (int c = 0; c < 4; ++c) {
+                if (!r.valid[static_cast<size_t>(4 * f + c)]) continue;
+                const uint8_t *frame = r.msc.data() + static_cast<size_t>(4 * f + c) * r.stride + sb.off;
+                if (sp->packet) {
+                    auto fe = h->db.fec_scheme.find(sp->subch_id);          // FIG 0/14 may arrive after the selection
+                    sp->pkt.set_fec(fe != h->db.fec_scheme.end() && fe->second == 1);
+                    sp->pkt.feed_frame(frame, static_cast<int>(fb));
+                    continue;
+                }
+                dabsdrAudioCBData_t d;
+                d.id = sp->id; d.ASCTy = static_cast<uint8_t>(sp->ascty); d.header.raw = 0;
+                if (sp->ascty == 0) d.header.mp2DRC = mp2_drc(!sp->mp2_half.empty(), frame, static_cast<int>(fb));
+                d.auLen = static_cast<uint16_t>(fb); d.pAuData = frame;
+                if (sp->id == DABSDR_ID_AUDIO_PRIMARY) h->audio_bytes_acc += d.auLen;
+                if (h->audio_cb) h->audio_cb(&d, h->audio_ctx);
+                if (sp->ascty == 0) feed_mp2_pad(sp, frame, static_cast<int>(fb));   // MPEG Layer II: PAD at the end of the audio frame
+            }
         }
     }
     if (h->period_log2 >= 0 && ++h->period_frames >= (1 << h->period_log2)) {
@@ -765,42 +853,119 @@ void after_step(dabsdr_s *h)
         p.syncLevel = lvl;
         p.snr10 = snr10;
         // inc is 2^-32 turn per sample at 2.048 MHz; the host wants Hz * 10
-        p.freqOffset = static_cast<int32_t>(std::llround(static_cast<double>(st.inc) * 2048000.0 * 10.0 / 4294967296.0));
+        p.freqOffset = static_cast<int32_t>(std::llround(static_cast<double>(rec.inc) * 2048000.0 * 10.0 / 4294967296.0));
         if (h->db.ens.utc_valid) {
             p.dateHoursMinutes = h->db.ens.date_hours_minutes & 0x7FFFFFFFu;
             p.secMsec = static_cast<uint16_t>((h->db.ens.seconds << 10) | h->db.ens.ms);
         }
         p.fibErrorCntr = static_cast<uint16_t>(h->fib_err_acc);
-        static const uint32_t kZero[6] = {0, 0, 0, 0, 0, 0};
-        const uint32_t *now = kZero, *was = h->last_sf_stats;
-        int prim_kbps = 0;
-        for (const auto &sp : h->sel)
-            if (sp->id == DABSDR_ID_AUDIO_PRIMARY) { now = sp->sf_stats; prim_kbps = sp->kbps; }
-        p.mscCrcOkCntr = static_cast<uint8_t>(now[1] - was[1]);
-        p.mscCrcErrorCntr = static_cast<uint8_t>(now[2] - was[2]);
-        p.rsUncorrectableCntr = static_cast<uint16_t>(now[4] - was[4]);
-        p.rsBitErrors = static_cast<uint16_t>(now[3] - was[3]);
-        p.rsBytes = static_cast<uint16_t>((now[0] - was[0]) * 120u * static_cast<unsigned>(prim_kbps / 8));
+        p.mscCrcOkCntr = static_cast<uint8_t>(h->per_au_ok);
+        p.mscCrcErrorCntr = static_cast<uint8_t>(h->per_au_bad);
+        p.rsUncorrectableCntr = static_cast<uint16_t>(h->per_rs_fail);
+        p.rsBitErrors = static_cast<uint16_t>(h->per_rs_corr);
+        p.rsBytes = static_cast<uint16_t>(h->per_sf * 120u * static_cast<unsigned>(h->per_kbps / 8));
         p.audioServiceBytes = static_cast<uint16_t>(h->audio_bytes_acc);
-        std::memcpy(h->last_sf_stats, now, sizeof h->last_sf_stats);
+        h->per_sf = h->per_au_ok = h->per_au_bad = h->per_rs_corr = h->per_rs_fail = 0;
         h->audio_bytes_acc = 0;
         notify(h, DABSDR_NID_PERIODIC, DABSDR_NSTAT_SUCCESS, &p, sizeof p);
         h->period_frames = 0; h->fib_err_acc = 0;
     }
 }
 
+// turn every fetched step into callbacks.  A callback chain may fetch further steps (a reconfiguration drains the
+// context: apply_selections), which land at the end of h->done and are served by the same loop.
+void deliver(dabsdr_s *h)
+{
+    while (!h->done.empty()) {
+        StepResults r = std::move(h->done.front());
+        h->done.pop_front();
+        // the device reports the lock state at the end of a step; inside a step the same rule runs here (k_finish: a locked
+        // receiver stays locked until four frames in a row have come without a phase reference symbol)
+        int bad = h->prev_bad;
+        for (int f = 0; f < r.n_frames; ++f) {
+            bad = (r.rec[static_cast<size_t>(f)].flags & 1) ? 0 : bad + 1;
+            const bool locked = f == r.n_frames - 1 ? r.st.locked != 0 : (h->locked_hint && bad < 4);
+            deliver_frame(h, r, f, locked);
+        }
+        h->prev_bad = r.st.bad;
+        h->locked_hint = r.st.locked != 0;
+        // gain hysteresis on the level the GPU saw (int16 units after the gain)
+        if (r.peak > 30000) --h->gain_shift;
+        else if (r.peak > 0 && r.peak < 256 && h->gain_shift < 40) ++h->gain_shift;
+    }
+}
+
+std::vector<SubSnap> snapshot_selections(const dabsdr_s *h)
+{
+    std::vector<SubSnap> v;
+    size_t off = 0;
+    for (const auto &sp : h->sel) {
+        SubSnap sb;
+        sb.serial = sp->serial; sb.kbps = sp->kbps; sb.off = off;
+        sb.dabplus = !sp->packet && sp->ascty == 63;
+        off += static_cast<size_t>(3 * sp->kbps);
+        v.push_back(std::move(sb));
+    }
+    return v;
+}
+
+// hand n complex float samples at `src` (page-locked) to the GPU and decode what is complete.
+//   async: the copy is queued and the step left in flight (the caller fills the other buffer meanwhile);
+//   otherwise everything is waited for and delivered before returning.
+void submit(dabsdr_s *h, const float *src, int64_t n, bool async)
+{
+    if (!h->ctx) return;
+    drain(h);                                                            // at most one step in flight
+    const float gain = std::ldexp(1.0f, h->gain_shift);
+    if (h->gain_epochs.empty() || h->gain_epochs.back().second != h->gain_shift) {
+        h->gain_epochs.emplace_back(h->pushed, h->gain_shift);
+        if (h->gain_epochs.size() > 16) h->gain_epochs.pop_front();
+    }
+    const int64_t rc = dabx_push_resampled_from(h->ctx, 0, src, n, DABX_FMT_F32, 2048000.0, gain, async ? DABX_SRC_PINNED : DABX_SRC_HOST);
+    if (rc < 0) { if (!async) deliver(h); return; }                      // (overrun: cannot happen with a ring of kRingFrames)
+    h->pushed += rc;
+    for (;;) {
+        const int avail = h->ctx ? dabx_frames_available(h->ctx) : 0;
+        if (avail < 1 || h->exit_req.load()) break;
+        const int nf = std::min(avail, kMaxBatch);
+        if (dabx_process_async(h->ctx, nf) != DABX_OK) break;
+        h->inflight = true;
+        h->inflight_frames = nf;
+        h->inflight_shift = h->gain_shift;
+        h->inflight_subs = snapshot_selections(h);
+        if (async) break;                                                // one step; what is left joins the next buffer
+        drain(h);
+        deliver(h);
+    }
+    if (!async) deliver(h);
+}
+
 void worker_loop(dabsdr_s *h);
 void worker_main(dabsdr_s *h)
 {
     pthread_setname_np(pthread_self(), "dabsdr");
+    // dabsdrDeinit may cancel this thread when it sits in the host's input callback for good; nowhere else (never inside a
+    // HIP call or a notification): cancellation is enabled around that call only
+    int old;
+    pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &old);
     struct Done { dabsdr_s *h; ~Done() { h->worker_done.store(true); } } done{h};     // also when the thread is cancelled
     worker_loop(h);
 }
 
+void pull(dabsdr_s *h, float *dst, int n)
+{
+    int old;
+    const auto t0 = std::chrono::steady_clock::now();
+    pthread_setcancelstate(PTHREAD_CANCEL_ENABLE, &old);
+    h->input(dst, static_cast<uint16_t>(n));
+    pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &old);
+    // how fast the host delivers: a frame's worth of this call's time, smoothed (1/8 per chunk)
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * (static_cast<double>(DABX_FRAME_SAMPLES) / n);
+    h->pull_s += (dt - h->pull_s) * 0.125;
+}
+
 void worker_loop(dabsdr_s *h)
 {
-    h->fbuf.resize(2 * kPullChunk);
-    h->sbuf.resize(2 * kPullChunk);
     // requests are served between input calls (every 8 ms of signal), like the reference, whose
     // reads never exceed one OFDM symbol: a host that paces or gates its input still gets answers
     auto serve = [h](bool may_block) -> bool {
@@ -810,58 +975,50 @@ void worker_loop(dabsdr_s *h)
             if (may_block && h->queue.empty()) h->cv.wait(lk, [&] { return !h->queue.empty() || h->exit_req.load(); });
             todo.swap(h->queue);
         }
+        if (!todo.empty()) { drain(h); deliver(h); }                     // answers come after what was decoded before the question
         for (const Request &r : todo) {
             if (r.kind == Req::Exit) return false;
             handle_request(h, r);
         }
         return true;
     };
+    const size_t buf_floats = 2 * static_cast<size_t>(kMaxBatch) * DABX_FRAME_SAMPLES;
     while (!h->exit_req.load()) {
         if (!serve(h->frequency == 0)) return;
         if (h->frequency == 0 || !h->ctx || !h->input) continue;
-        // one transmission frame of input — converted chunk by chunk into one host buffer and handed to the GPU in a single
-        // copy (a copy per 8 ms chunk cost twelve synchronisations per frame) — then decode whatever is complete
-        if (!h->frame_s16) h->frame_s16 = static_cast<int16_t *>(dabx_alloc_pinned(2 * static_cast<size_t>(DABX_FRAME_SAMPLES) * sizeof(int16_t)));
-        if (!h->frame_s16) return;
-        bool complete = true;
-        const bool chunked = !h->locked_hint;                            // acquiring: chunk by chunk (synchronous copies, steps in between)
-        auto run_steps = [h]() -> bool {
-            bool stepped = false;
-            while (!h->exit_req.load() && h->ctx && dabx_frames_available(h->ctx) >= 1) {
-                if (dabx_process(h->ctx, 1) != DABX_OK) break;           // waits for the queued copy of the frame buffer
-                stepped = true;
-                after_step(h);
-            }
-            return stepped;
-        };
-        for (int got = 0; got < DABX_FRAME_SAMPLES; got += kPullChunk) {
-            if (h->exit_req.load() || (got && !serve(false))) { if (!h->exit_req.load()) return; complete = false; break; }
-            if (h->frequency == 0 || !h->ctx) { complete = false; break; }
-            h->input(h->fbuf.data(), static_cast<uint16_t>(kPullChunk));
-            if (!h->gain_set) {                                         // the first frame after a tune fixes the gain
-                h->first_frame.insert(h->first_frame.end(), h->fbuf.begin(), h->fbuf.end());
-                if (h->first_frame.size() < 2 * static_cast<size_t>(DABX_FRAME_SAMPLES)) continue;
-                h->gain_shift = choose_shift(h->first_frame.data(), h->first_frame.size());
-                h->gain_set = true;
-                h->frame_fill = 0; h->frame_peak = 0.0f;
-                for (size_t o = 0; o < h->first_frame.size(); o += 2 * kPullChunk)
-                    convert(h, h->first_frame.data() + o, h->frame_s16 + o, 2 * kPullChunk);
-                h->first_frame.clear(); h->first_frame.shrink_to_fit();
-                (void)dabx_push(h->ctx, 0, h->frame_s16, DABX_FRAME_SAMPLES, DABX_SRC_PINNED);
-                (void)dabx_flush_copies(h->ctx);                        // the buffer is refilled next
-                complete = false;                                       // this frame has gone; start collecting the next one
-                break;
-            }
-            convert(h, h->fbuf.data(), h->frame_s16 + 2 * static_cast<size_t>(got), 2 * kPullChunk);
-            if (chunked) {
-                if (dabx_push(h->ctx, 0, h->frame_s16 + 2 * static_cast<size_t>(got), kPullChunk, DABX_SRC_HOST) != DABX_OK) { complete = false; break; }
-                (void)run_steps();
-                if (!h->ctx) { complete = false; break; }                // a reset inside after_step
-            }
+        for (float *&b : h->fbuf)
+            if (!b && !(b = static_cast<float *>(dabx_alloc_pinned(buf_floats * sizeof(float))))) return;
+        float *buf = h->fbuf[h->cur];
+        if (h->fill == 0 && h->buf_busy[h->cur]) { (void)dabx_flush_copies(h->ctx); h->buf_busy[0] = h->buf_busy[1] = false; }
+        pull(h, buf + 2 * static_cast<size_t>(h->fill), kPullChunk);
+        h->fill += kPullChunk;
+        if (!h->gain_set) {                                              // the first frame with a signal after a tune fixes the gain
+            if (h->fill < DABX_FRAME_SAMPLES) continue;
+            h->gain_set = choose_shift(buf, 2 * static_cast<size_t>(h->fill), h->gain_shift);
+            if (h->gain_set) submit(h, buf, h->fill, false);
+            h->fill = 0;                                                 // (a silent frame is dropped: nothing to decode in it)
+            continue;
         }
-        if (chunked) continue;
-        if (complete && h->gain_set && h->first_frame.empty() && dabx_push(h->ctx, 0, h->frame_s16, DABX_FRAME_SAMPLES, DABX_SRC_PINNED) != DABX_OK) continue;
-        if (!run_steps() && h->ctx) dabx_flush_copies(h->ctx);   // the frame buffer is refilled next: its copy must have left it
+        if (!h->locked_hint) {                                           // acquiring: every chunk at once, steps in between
+            submit(h, buf, h->fill, false);
+            h->fill = 0;
+            continue;
+        }
+        // locked: whole frames, as many per step as arrive within 48 ms (one when the host paces its input at real time)
+        h->batch = std::max(1, std::min(kMaxBatch, static_cast<int>(0.048 / std::max(h->pull_s, 1e-6))));
+        h->pipelined = h->pull_s < 0.0096;
+        if (h->fill < h->batch * DABX_FRAME_SAMPLES && h->fill + kPullChunk <= kMaxBatch * DABX_FRAME_SAMPLES) continue;
+        if (h->pipelined) {
+            // the step of the buffer filled before this one has had a whole fill to finish: fetch it, start this one,
+            // then turn the fetched one into callbacks while the GPU works
+            submit(h, buf, h->fill, true);
+            h->buf_busy[h->cur] = true;
+            h->cur ^= 1;
+            deliver(h);
+        } else {
+            submit(h, buf, h->fill, false);
+        }
+        h->fill = 0;
     }
 }
 
@@ -884,7 +1041,7 @@ uint8_t dabsdrInit(dabsdrHandle_t *handle)
     if (!handle) return EXIT_FAILURE;
     dabsdr_s *h = new (std::nothrow) dabsdr_s;
     if (!h) return EXIT_FAILURE;
-    dabx_config_t cfg = {1, DABX_FMT_S16, 8LL * DABX_FRAME_SAMPLES, 1, 0};
+    dabx_config_t cfg = {1, DABX_FMT_S16, static_cast<int64_t>(kRingFrames) * DABX_FRAME_SAMPLES, kMaxBatch, 0};
     if (dabx_create(&cfg, &h->ctx) != DABX_OK) {     // no GPU: fail loudly, there is no CPU path
         delete h;
         *handle = nullptr;
@@ -925,7 +1082,8 @@ void dabsdrDeinit(dabsdrHandle_t *handle)
         h->worker.join();
     }
     if (h->ctx) dabx_destroy(h->ctx);
-    if (h->frame_s16) dabx_free_pinned(h->frame_s16);
+    for (float *b : h->fbuf)
+        if (b) dabx_free_pinned(b);
     delete h;
     *handle = nullptr;
 }

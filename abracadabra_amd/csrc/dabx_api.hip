@@ -91,7 +91,7 @@ struct dabx_ctx {
     // single-stream contexts (the legacy 24-function path: one ensemble, one frame per step) get their small per-step
     // results with the step itself, into page-locked memory: the getters then cost no HIP call (each synchronous
     // device-to-host copy of a few hundred bytes took ~22 us, eight of them per 96 ms frame)
-    uint8_t *h_res = nullptr;               // [F][384] fib | [F][12] fib_ok | [F][64] sync | [2][2048] float spectra
+    uint8_t *h_res = nullptr;               // [F][384] fib | [F][12] fib_ok | [F][64] sync | [2048] float spectrum | [F][2048] null spectra
     bool res_valid = false;
 
     std::vector<StreamHost> streams;
@@ -115,6 +115,12 @@ struct dabx_ctx {
     rs::State *d_rs_state = nullptr;        // [S], zeroed
     uint8_t *d_rs_in = nullptr; float *d_rs_mu = nullptr; int32_t *d_rs_seg = nullptr; float2 *d_rs_A = nullptr, *d_rs_x = nullptr;
     size_t rs_in_cap = 0, rs_mu_cap = 0, rs_seg_cap = 0, rs_A_cap = 0;
+    struct RsSched { float *mu = nullptr; int32_t *seg = nullptr; size_t cap_mu = 0, cap_seg = 0; hipEvent_t ev = nullptr; } rs_sched[2];
+    int rs_slot = 0, rs_last_async = -1;
+    // largest |I|, |Q| the converters wrote since the step before last was submitted: [2][S] on the device (the pushes between two
+    // steps use slot step_count & 1), latched into h_peak [S] by the step that follows them
+    uint32_t *d_peak = nullptr, *h_peak = nullptr;
+    uint64_t step_count = 0;
     std::mutex mu;
 
     // bytes per stream in d_ring: the ring itself plus a mirror of its first DABX_RING_MIRROR samples behind its end, so
@@ -373,7 +379,7 @@ static int create_body(dabx_ctx *c, const dabx_config_t *cfg)
     ALLOC(c->d_sub, S * 64 * sizeof(DevSub));
 #undef ALLOC
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_state), S * sizeof(DevState)));
-    if (S == 1) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_res), F * (384 + 12 + sizeof(DevSync)) + 2 * 2048 * sizeof(float)));
+    if (S == 1) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_res), F * (384 + 12 + sizeof(DevSync)) + (1 + F) * 2048 * sizeof(float)));
     std::memset(c->h_state, 0, S * sizeof(DevState));
     c->h_sub.assign(S * 64, DevSub{});
     int rc = upload_tables(c);
@@ -396,6 +402,13 @@ void dabx_destroy(dabx_ctx *c)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_peak) (void)hipHostFree(c->h_peak);
+    if (c->d_peak) (void)hipFree(c->d_peak);
+    for (auto &sl : c->rs_sched) {
+        if (sl.mu) (void)hipHostFree(sl.mu);
+        if (sl.seg) (void)hipHostFree(sl.seg);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -499,10 +512,34 @@ int dabx_push_all(dabx_ctx *c, const void *src, size_t stride, int64_t n, int ki
     return DABX_OK;
 }
 
-int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain)
+// Host side of the Farrow schedule for an asynchronous push: two page-locked slots (mu per input sample, the first sample of
+// every segment), each guarded by an event recorded behind the copies that read it.
+static int rs_sched_slot(dabx_ctx *c, size_t n_mu, size_t n_seg, float *&mu, int32_t *&seg, int &slot)
+{
+    slot = c->rs_slot ^= 1;
+    auto &sl = c->rs_sched[slot];
+    if (sl.ev) HIPCHK(hipEventSynchronize(sl.ev));                      // the copies queued from this slot two pushes ago
+    else HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (n_mu > sl.cap_mu) {
+        if (sl.mu) (void)hipHostFree(sl.mu);
+        sl.mu = nullptr; sl.cap_mu = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&sl.mu), (n_mu + n_mu / 2 + 1024) * sizeof(float)));
+        sl.cap_mu = n_mu + n_mu / 2 + 1024;
+    }
+    if (n_seg > sl.cap_seg) {
+        if (sl.seg) (void)hipHostFree(sl.seg);
+        sl.seg = nullptr; sl.cap_seg = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&sl.seg), (n_seg + n_seg / 2 + 1024) * sizeof(int32_t)));
+        sl.cap_seg = n_seg + n_seg / 2 + 1024;
+    }
+    mu = sl.mu; seg = sl.seg;
+    return DABX_OK;
+}
+
+int64_t dabx_push_resampled_from(dabx_ctx *c, int s, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain, int kind)
 {
     if (!valid_stream(c, s) || n < 0 || (n && !src) || (src_fmt != DABX_FMT_S16 && src_fmt != DABX_FMT_F32) || !(in_rate_hz >= 2048000.0) ||
-        in_rate_hz > 32768000.0 || n > (1 << 28) || c->cfg.fmt != DABX_FMT_S16)
+        in_rate_hz > 32768000.0 || n > (1 << 28) || c->cfg.fmt != DABX_FMT_S16 || kind < DABX_SRC_HOST || kind > DABX_SRC_PINNED)
         return DABX_E_ARG;
     const bool ds2 = in_rate_hz == 4096000.0, copy = in_rate_hz == 2048000.0;
     if (ds2 && (n & 1)) return DABX_E_ARG;
@@ -511,18 +548,34 @@ int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int 
     auto &sh = c->streams[s];
     const int64_t len = c->cfg.ring_samples;
     const size_t bpc = src_fmt == DABX_FMT_S16 ? 4 : 8;                  // bytes per complex input sample
-    hipStream_t q = c->stream;
+    // DABX_SRC_PINNED: staging copy and converter kernels go to the copy stream and overlap with a decode step in flight;
+    // the carried filter state lives in device memory and is handed from launch to launch in stream order, so a change of
+    // the source kind first drains the stream the previous push used
+    const bool async = kind == DABX_SRC_PINNED;
+    hipStream_t q = async ? c->copy_stream : c->stream;
+    if (c->rs_last_async != static_cast<int>(async)) {
+        if (c->rs_last_async >= 0) HIPCHK(hipStreamSynchronize(c->rs_last_async ? c->copy_stream : c->stream));
+        c->rs_last_async = static_cast<int>(async);
+    }
     if (!c->d_rs_state) {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_rs_state), c->cfg.n_streams * sizeof(rs::State)));
         HIPCHK(hipMemset(c->d_rs_state, 0, c->cfg.n_streams * sizeof(rs::State)));
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_rs_x), rs::FW_M * sizeof(float2)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_peak), 2 * static_cast<size_t>(c->cfg.n_streams) * sizeof(uint32_t)));
+        HIPCHK(hipMemset(c->d_peak, 0, 2 * static_cast<size_t>(c->cfg.n_streams) * sizeof(uint32_t)));
     }
     if (n == 0) return 0;
     int rc;
-    if ((rc = grow(c->d_rs_in, c->rs_in_cap, static_cast<size_t>(n) * bpc))) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_rs_in, src, static_cast<size_t>(n) * bpc, hipMemcpyHostToDevice, q));
+    if (static_cast<size_t>(n) * bpc > c->rs_in_cap) {               // growing frees the old buffer: nothing may still read it
+        HIPCHK(hipStreamSynchronize(q));
+        if ((rc = grow(c->d_rs_in, c->rs_in_cap, static_cast<size_t>(n) * bpc))) return rc;
+    }
+    const void *in = c->d_rs_in;
+    if (kind == DABX_SRC_DEVICE) in = src;                               // already on this GPU: converted in place
+    else HIPCHK(hipMemcpyAsync(c->d_rs_in, src, static_cast<size_t>(n) * bpc, hipMemcpyHostToDevice, q));
     rs::State *st = c->d_rs_state + s;
     short2 *ring = reinterpret_cast<short2 *>(c->ring_of(s));
+    uint32_t *peak = c->d_peak + static_cast<size_t>(c->step_count & 1) * c->cfg.n_streams + s;
     int64_t n_out = 0;
     // the reference picks the converter by rate (inputdevicesrc.cpp:33-47)
     if (copy || ds2) {
@@ -530,54 +583,76 @@ int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int 
         if (sh.wr + n_out - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
         const unsigned blocks = static_cast<unsigned>((n_out + 255) / 256);
         if (copy) {
-            if (src_fmt == DABX_FMT_S16) hipLaunchKernelGGL(rs::k_resample_copy<1>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), ring, len, sh.wr, gain);
-            else hipLaunchKernelGGL(rs::k_resample_copy<2>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), ring, len, sh.wr, gain);
+            if (src_fmt == DABX_FMT_S16) hipLaunchKernelGGL(rs::k_resample_copy<1>, dim3(blocks), dim3(256), 0, q, in, static_cast<int>(n_out), ring, len, sh.wr, gain, peak);
+            else hipLaunchKernelGGL(rs::k_resample_copy<2>, dim3(blocks), dim3(256), 0, q, in, static_cast<int>(n_out), ring, len, sh.wr, gain, peak);
         } else if (src_fmt == DABX_FMT_S16) {
-            hipLaunchKernelGGL(rs::k_resample_ds2<1>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), st, ring, len, sh.wr, gain);
-            hipLaunchKernelGGL(rs::k_ds2_tail<1>, dim3(1), dim3(64), 0, q, c->d_rs_in, n, st);
+            hipLaunchKernelGGL(rs::k_resample_ds2<1>, dim3(blocks), dim3(256), 0, q, in, static_cast<int>(n_out), st, ring, len, sh.wr, gain, peak);
+            hipLaunchKernelGGL(rs::k_ds2_tail<1>, dim3(1), dim3(64), 0, q, in, n, st);
         } else {
-            hipLaunchKernelGGL(rs::k_resample_ds2<2>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, static_cast<int>(n_out), st, ring, len, sh.wr, gain);
-            hipLaunchKernelGGL(rs::k_ds2_tail<2>, dim3(1), dim3(64), 0, q, c->d_rs_in, n, st);
+            hipLaunchKernelGGL(rs::k_resample_ds2<2>, dim3(blocks), dim3(256), 0, q, in, static_cast<int>(n_out), st, ring, len, sh.wr, gain, peak);
+            hipLaunchKernelGGL(rs::k_ds2_tail<2>, dim3(1), dim3(64), 0, q, in, n, st);
         }
     } else {
         // the schedule of the transposed Farrow structure does not depend on the data: mu <- mu - R, a dump (one output)
-        // whenever it turns negative (inputdevicesrc.cpp:241-245).  The recursion is serial in float, so the host runs
-        // it ahead; the kernels do the arithmetic on the samples.
+        // whenever it turns negative (inputdevicesrc.cpp:241-245).  The recursion is serial in float (every step rounds), so
+        // the host runs it ahead into page-locked memory; the kernels do the arithmetic on the samples.
         const float R = static_cast<float>(2048e3 / static_cast<double>(static_cast<float>(in_rate_hz)));
-        std::vector<float> mu(static_cast<size_t>(n));
-        std::vector<int32_t> seg(1, 0);
+        float *mu = nullptr;
+        int32_t *seg = nullptr;
+        int slot = 0;
+        if ((rc = rs_sched_slot(c, static_cast<size_t>(n), static_cast<size_t>(n) + 2, mu, seg, slot))) return rc;
         float m = sh.rs_mu;
+        size_t n_seg = 1;
+        seg[0] = 0;
         for (int64_t k = 0; k < n; ++k) {
             m = m - R;
-            if (m < 0) { m = m + 1.0f; seg.push_back(static_cast<int32_t>(k)); }
+            if (m < 0) { m = m + 1.0f; seg[n_seg++] = static_cast<int32_t>(k); }
             mu[static_cast<size_t>(k)] = m;
         }
-        const int n_done = static_cast<int>(seg.size()) - 1;
+        const int n_done = static_cast<int>(n_seg) - 1;
         n_out = n_done;
         if (sh.wr + n_out - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
-        if ((rc = grow(c->d_rs_mu, c->rs_mu_cap, mu.size())) || (rc = grow(c->d_rs_seg, c->rs_seg_cap, seg.size())) ||
-            (rc = grow(c->d_rs_A, c->rs_A_cap, static_cast<size_t>(n_done + 1) * rs::FW_N)))
-            return rc;
-        HIPCHK(hipMemcpyAsync(c->d_rs_mu, mu.data(), mu.size() * sizeof(float), hipMemcpyHostToDevice, q));
-        HIPCHK(hipMemcpyAsync(c->d_rs_seg, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, q));
+        const size_t need_A = static_cast<size_t>(n_done + 1) * rs::FW_N;
+        if (static_cast<size_t>(n) > c->rs_mu_cap || n_seg > c->rs_seg_cap || need_A > c->rs_A_cap) {
+            HIPCHK(hipStreamSynchronize(q));
+            if ((rc = grow(c->d_rs_mu, c->rs_mu_cap, static_cast<size_t>(n))) || (rc = grow(c->d_rs_seg, c->rs_seg_cap, n_seg)) ||
+                (rc = grow(c->d_rs_A, c->rs_A_cap, need_A)))
+                return rc;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_rs_mu, mu, static_cast<size_t>(n) * sizeof(float), hipMemcpyHostToDevice, q));
+        HIPCHK(hipMemcpyAsync(c->d_rs_seg, seg, n_seg * sizeof(int32_t), hipMemcpyHostToDevice, q));
+        HIPCHK(hipEventRecord(c->rs_sched[slot].ev, q));
         const unsigned blocks = static_cast<unsigned>((n_done + 255) / 256);
         if (src_fmt == DABX_FMT_S16) {
-            if (n_done) hipLaunchKernelGGL(rs::k_farrow_segments<1>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, st, c->d_rs_A);
-            hipLaunchKernelGGL(rs::k_farrow_open<1>, dim3(1), dim3(64), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, n, st, c->d_rs_x);
+            if (n_done) hipLaunchKernelGGL(rs::k_farrow_segments<1>, dim3(blocks), dim3(256), 0, q, in, c->d_rs_seg, c->d_rs_mu, n_done, st, c->d_rs_A);
+            hipLaunchKernelGGL(rs::k_farrow_open<1>, dim3(1), dim3(64), 0, q, in, c->d_rs_seg, c->d_rs_mu, n_done, n, st, c->d_rs_x);
         } else {
-            if (n_done) hipLaunchKernelGGL(rs::k_farrow_segments<2>, dim3(blocks), dim3(256), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, st, c->d_rs_A);
-            hipLaunchKernelGGL(rs::k_farrow_open<2>, dim3(1), dim3(64), 0, q, c->d_rs_in, c->d_rs_seg, c->d_rs_mu, n_done, n, st, c->d_rs_x);
+            if (n_done) hipLaunchKernelGGL(rs::k_farrow_segments<2>, dim3(blocks), dim3(256), 0, q, in, c->d_rs_seg, c->d_rs_mu, n_done, st, c->d_rs_A);
+            hipLaunchKernelGGL(rs::k_farrow_open<2>, dim3(1), dim3(64), 0, q, in, c->d_rs_seg, c->d_rs_mu, n_done, n, st, c->d_rs_x);
         }
-        if (n_done) hipLaunchKernelGGL(rs::k_farrow_outputs, dim3(blocks), dim3(256), 0, q, c->d_rs_A, n_done, st, ring, len, sh.wr, R, gain);
+        if (n_done) hipLaunchKernelGGL(rs::k_farrow_outputs, dim3(blocks), dim3(256), 0, q, c->d_rs_A, n_done, st, ring, len, sh.wr, R, gain, peak);
         hipLaunchKernelGGL(rs::k_farrow_tail, dim3(1), dim3(64), 0, q, c->d_rs_A, n_done, st, c->d_rs_x);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(q));             // the host vectors go out of scope
         sh.rs_mu = m;
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(q));                 // the caller may reuse its buffer
+    if (async) c->copies_queued = true;                  // the next step waits for the copy stream
+    else HIPCHK(hipStreamSynchronize(q));                // the caller may reuse its buffer
     sh.wr += n_out;
     return n_out;
+}
+
+int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain)
+{
+    return dabx_push_resampled_from(c, s, src, n, src_fmt, in_rate_hz, gain, DABX_SRC_HOST);
+}
+
+int dabx_get_input_peak(dabx_ctx *c, int s, int32_t *peak)
+{
+    if (!valid_stream(c, s) || !peak) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->pending) return DABX_E_ARG;
+    *peak = c->h_peak ? static_cast<int32_t>(c->h_peak[s]) : 0;
+    return DABX_OK;
 }
 
 int dabx_read_ring(dabx_ctx *c, int s, int64_t from, int64_t n, void *dst)
@@ -672,6 +747,13 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
         HIPCHK(hipStreamWaitEvent(q, c->copy_done, 0));
         c->copies_queued = false;
     }
+    if (c->d_peak) {                        // the converters' peak over the pushes since the previous step was submitted
+        uint32_t *slot = c->d_peak + static_cast<size_t>(c->step_count & 1) * S;
+        if (!c->h_peak) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_peak), static_cast<size_t>(S) * sizeof(uint32_t)));
+        HIPCHK(hipMemcpyAsync(c->h_peak, slot, static_cast<size_t>(S) * sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+        HIPCHK(hipMemsetAsync(slot, 0, static_cast<size_t>(S) * sizeof(uint32_t), q));   // next written by the pushes after the NEXT step's submission
+    }
+    ++c->step_count;
     const bool u8 = c->cfg.fmt == DABX_FMT_U8;
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], q));
     if (u8) hipLaunchKernelGGL(k_null_search<0>, dim3(S), dim3(256), 0, q, d);
@@ -710,7 +792,7 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
         HIPCHK(hipMemcpyAsync(p + F * 396, c->d_sync, n * sizeof(DevSync), hipMemcpyDeviceToHost, q));
         float *sp = reinterpret_cast<float *>(p + F * (396 + sizeof(DevSync)));
         if (c->d_spectrum) HIPCHK(hipMemcpyAsync(sp, c->d_spectrum, 2048 * sizeof(float), hipMemcpyDeviceToHost, q));
-        if (c->d_null_spectrum) HIPCHK(hipMemcpyAsync(sp + 2048, c->d_null_spectrum, 2048 * sizeof(float), hipMemcpyDeviceToHost, q));
+        if (c->d_null_spectrum) HIPCHK(hipMemcpyAsync(sp + 2048, c->d_null_spectrum, n * 2048 * sizeof(float), hipMemcpyDeviceToHost, q));
         c->res_valid = true;
     }
     c->pending = true;
@@ -888,11 +970,12 @@ int dabx_enable_spectrum(dabx_ctx *c, int mask)
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (c->pending) return DABX_E_ARG;
-    const size_t bytes = static_cast<size_t>(c->cfg.n_streams) * 2048 * sizeof(float);
     c->res_valid = false;                            // the result mirror of the last step does not hold what is enabled now
     float **bufs[2] = {&c->d_spectrum, &c->d_null_spectrum};
     for (int k = 0; k < 2; ++k) {
         const bool want = (mask >> k) & 1;
+        // the PRS spectrum of a step's last frame; the null-symbol spectrum of every frame
+        const size_t bytes = static_cast<size_t>(c->cfg.n_streams) * (k ? c->cfg.max_frames : 1) * 2048 * sizeof(float);
         if (want && !*bufs[k]) {
             HIPCHK(hipMalloc(reinterpret_cast<void **>(bufs[k]), bytes));
             HIPCHK(hipMemset(*bufs[k], 0, bytes));
@@ -916,9 +999,18 @@ int dabx_get_spectrum(dabx_ctx *c, int s, float *power)
 int dabx_get_null_spectrum(dabx_ctx *c, int s, float *power)
 {
     GETTER_PROLOGUE
-    if (!power || !c->d_null_spectrum) return DABX_E_ARG;
-    if (c->res_valid) { std::memcpy(power, c->h_res + F * (396 + sizeof(DevSync)) + 2048 * sizeof(float), 2048 * sizeof(float)); return DABX_OK; }
-    HIPCHK(hipMemcpy(power, c->d_null_spectrum + static_cast<size_t>(s) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
+    if (!power || !c->d_null_spectrum || n < 1) return DABX_E_ARG;
+    if (c->res_valid) { std::memcpy(power, c->h_res + F * (396 + sizeof(DevSync)) + n * 2048 * sizeof(float), 2048 * sizeof(float)); return DABX_OK; }
+    HIPCHK(hipMemcpy(power, c->d_null_spectrum + (static_cast<size_t>(s) * F + n - 1) * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_null_spectra(dabx_ctx *c, int s, float *power)
+{
+    GETTER_PROLOGUE
+    if (!power || !c->d_null_spectrum || n < 1) return DABX_E_ARG;
+    if (c->res_valid) { std::memcpy(power, c->h_res + F * (396 + sizeof(DevSync)) + 2048 * sizeof(float), n * 2048 * sizeof(float)); return DABX_OK; }
+    HIPCHK(hipMemcpy(power, c->d_null_spectrum + static_cast<size_t>(s) * F * 2048, n * 2048 * sizeof(float), hipMemcpyDeviceToHost));
     return DABX_OK;
 }
 
@@ -968,6 +1060,19 @@ int dabx_get_superframe_stats(dabx_ctx *c, int s, int sub, uint32_t stats[6])
     const int i = find_sf(c, s, sub);
     if (i < 0) return DABX_E_ARG;
     HIPCHK(hipMemcpy(stats, reinterpret_cast<const uint8_t *>(c->d_sf_state + i) + offsetof(DevSfState, stats), 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return DABX_OK;
+}
+
+int dabx_get_superframe_pos(dabx_ctx *c, int s, int sub, uint32_t pos[2])
+{
+    GETTER_PROLOGUE
+    if (!pos || c->sf_dirty) return DABX_E_ARG;
+    const int i = find_sf(c, s, sub);
+    if (i < 0) return DABX_E_ARG;
+    DevSfState st;
+    HIPCHK(hipMemcpy(&st, c->d_sf_state + i, sizeof(int32_t) * 4, hipMemcpyDeviceToHost));
+    pos[0] = st.frames_seen;
+    pos[1] = static_cast<uint32_t>(st.carry);
     return DABX_OK;
 }
 

@@ -41,7 +41,7 @@ struct DevWork {        // one Viterbi codeword = one wave
     int16_t frame;
     int8_t c;           // FIC codeword 0..3 or CIF 0..3
     int8_t sub;         // -1 = FIC
-    uint32_t scratch;   // the codeword's block of dec_scratch, in units of 64 words (= the decision word of every lane for 30 steps)
+    uint32_t scratch;   // the codeword's block of dec_scratch, in units of 64 words (= the decision word of every lane for 24 steps)
     uint32_t nsteps;
 };
 
@@ -102,9 +102,9 @@ struct DevCtx {
     const DevSub *sub;          // [S][64]
     const uint32_t *stepinfo;   // pooled depuncturing maps
     const uint32_t *prbs;       // energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
-    uint32_t *dec_scratch;      // decision words of k_viterbi: 64 words per 30 trellis steps and codeword
+    uint32_t *dec_scratch;      // decision words of k_viterbi: 64 words per 24 trellis steps and codeword (fallback, see k_viterbi)
     float *spectrum;            // [S][2048] |FFT|^2 of the last frame's PRS window, natural bin order; may be null
-    float *null_spectrum;       // [S][2048] same for 2048 samples in the middle of the null symbol (TII); may be null
+    float *null_spectrum;       // [S][F][2048] same for 2048 samples in the middle of every frame's null symbol (noise level, TII); may be null
     int64_t ring_len;           // samples
     size_t ring_bytes;          // bytes per stream
     int32_t n_streams, max_frames, ti_slots, msc_stride, fic_info_off;

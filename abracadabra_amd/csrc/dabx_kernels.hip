@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     }   // pass
     // optional spectrum of the null symbol (TII carriers; reference: DABSDR_SPECT_NULL / dabsdrNtfTii_t):
     // 2048 samples centred in the 2656-sample null symbol, de-rotated like the PRS window
-    if (C.null_spectrum && f == n_frames - 1) {
+    // (every frame of the step: the host's noise estimate is per frame)
+    if (C.null_spectrum) {
         __syncthreads();
         const int64_t n0 = pos_f + (TNULL - TU) / 2;
         load_window<FMT>(v, T, ring, C.ring_len, wrap(n0, C.ring_len), 0u, inc, t);
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float a = v[e].r * v[e].r, b = v[e].i * v[e].i;
-            C.null_spectrum[(size_t)s * TU + T.bin_of_pos[8 * t + e]] = a + b;
+            C.null_spectrum[((size_t)s * C.max_frames + f) * TU + T.bin_of_pos[8 * t + e]] = a + b;
         }
     }
 }

@@ -59,10 +59,21 @@ __device__ __forceinline__ void ring_store(short2 *ring, int64_t ring_len, int64
     if (w < RING_MIRROR) ring[ring_len + w] = v;
 }
 
+// Largest |I|, |Q| among the samples a launch writes, folded into *peak (a per-stream word the host latches per decode
+// step: dabx_get_input_peak).  The legacy adapter's gain hysteresis needs it (dabsdr_shim.cpp).  Every thread of the wave
+// must call it (inactive threads with active = false).
+__device__ __forceinline__ void note_peak(uint32_t *peak, short2 v, bool active)
+{
+    int a = active ? max(abs((int)v.x), abs((int)v.y)) : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) a = max(a, __shfl_xor(a, d, 64));
+    if (peak && (threadIdx.x & 63) == 0 && a) atomicMax(peak, (uint32_t)a);
+}
+
 // one output per thread: y[n] = sum_c coef[c] (x[2n-42+2c] + x[2n-2c]) + 0.5 x[2n-21]
 template <int FMT>
 __global__ __launch_bounds__(256) void k_resample_ds2(const void *in, int n_out, const State *st, short2 *ring, int64_t ring_len, int64_t wr,
-                                                      float gain)
+                                                      float gain, uint32_t *peak)
 {
     __shared__ float2 x[2 * 256 + DS2_HIST];
     const int t = threadIdx.x, n0 = blockIdx.x * 256;
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void k_resample_ds2(const void *in, int n_out,
     }
     __syncthreads();
     const int n = n0 + t;
-    if (n >= n_out) return;
+    if (n >= n_out) { note_peak(peak, make_short2(0, 0), false); return; }
     float accI = 0.0f, accQ = 0.0f;
 #pragma unroll
     for (int c = 0; c < 11; ++c) {
@@ -94,7 +105,9 @@ __global__ __launch_bounds__(256) void k_resample_ds2(const void *in, int n_out,
         u = m.y * ds2_coef[11];
         accQ = accQ + u;
     }
-    ring_store(ring, ring_len, wr + n, to_s16(make_float2(accI, accQ), gain));
+    const short2 o16 = to_s16(make_float2(accI, accQ), gain);
+    ring_store(ring, ring_len, wr + n, o16);
+    note_peak(peak, o16, true);
 }
 
 // after the block: the history for the next call = the last 42 input samples (n_in even, >= 0)
@@ -111,11 +124,15 @@ __global__ void k_ds2_tail(const void *in, int64_t n_in, State *st)
 
 // pass-through (2048 kHz in): float or s16 -> the ring's s16
 template <int FMT>
-__global__ __launch_bounds__(256) void k_resample_copy(const void *in, int n, short2 *ring, int64_t ring_len, int64_t wr, float gain)
+__global__ __launch_bounds__(256) void k_resample_copy(const void *in, int n, short2 *ring, int64_t ring_len, int64_t wr, float gain, uint32_t *peak)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    ring_store(ring, ring_len, wr + k, to_s16(in_sample<FMT>(in, k), gain));
+    short2 v = make_short2(0, 0);
+    if (k < n) {
+        v = to_s16(in_sample<FMT>(in, k), gain);
+        ring_store(ring, ring_len, wr + k, v);
+    }
+    note_peak(peak, v, k < n);
 }
 
 // Transposed Farrow, pass 1: one thread per segment (the input samples integrated between two dumps).
@@ -159,9 +176,10 @@ __global__ __launch_bounds__(256) void k_farrow_segments(const void *in, const i
 // the order in which the reference's delay line y[] picks the contributions up.  n_done segments are complete (the last
 // segment of a call may still be open).
 __global__ __launch_bounds__(256) void k_farrow_outputs(const float2 *A, int n_done, const State *st, short2 *ring, int64_t ring_len, int64_t wr,
-                                                        float R, float gain)
+                                                        float R, float gain, uint32_t *peak)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    short2 o16 = make_short2(0, 0);
     if (j < n_done) {
         float yI = 0.0f, yQ = 0.0f;
 #pragma unroll
@@ -170,8 +188,10 @@ __global__ __launch_bounds__(256) void k_farrow_outputs(const float2 *A, int n_d
             const float2 a = s >= 0 ? A[(size_t)s * FW_N + i] : st->fw_a[FW_N - 1 + s][i];
             yI = yI + a.x; yQ = yQ + a.y;
         }
-        ring_store(ring, ring_len, wr + j, to_s16(make_float2(R * yI, R * yQ), gain));
+        o16 = to_s16(make_float2(R * yI, R * yQ), gain);
+        ring_store(ring, ring_len, wr + j, o16);
     }
+    note_peak(peak, o16, j < n_done);
 }
 
 // carry-over for the next call: A of the last five finished segments and the integrators of the open one

@@ -20,10 +20,10 @@ SYNC_DTYPE = np.dtype([("t_sym0", "<i8"), ("inc", "<i4"), ("flags", "<i4"), ("pe
 # every symbol include/dabx.h declares; tests check that the library exports them all
 DABX_SYMBOLS = [
     "dabx_create", "dabx_destroy", "dabx_strerror", "dabx_set_subchannels", "dabx_push", "dabx_push_all", "dabx_set_dabplus", "dabx_get_superframes", "dabx_get_superframe_stats", "dabx_alloc_pinned", "dabx_free_pinned", "dabx_ring_ptr",
-    "dabx_push_resampled", "dabx_read_ring", "dabx_flush_copies",
+    "dabx_push_resampled", "dabx_push_resampled_from", "dabx_get_input_peak", "dabx_get_superframe_pos", "dabx_read_ring", "dabx_flush_copies",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
-    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum",
+    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum", "dabx_get_null_spectra",
 ]
 
 

@@ -128,6 +128,15 @@ DABX_API int dabx_push_all(dabx_ctx *ctx, const void *src, size_t src_stride_byt
  *   appended to the ring, or a negative error code.  The reference's signal-level output is not produced. */
 #define DABX_FMT_F32 2
 DABX_API int64_t dabx_push_resampled(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain);
+/* The same with the source kinds of dabx_push.  DABX_SRC_PINNED: the staging copy and the converter kernels are queued on the
+ * context's copy stream and the call returns at once (the buffer must stay untouched until the next decode step has been
+ * waited for, or dabx_flush_copies); DABX_SRC_DEVICE: src is device memory of the context's GPU, converted in place.
+ * This is how the legacy adapter hands the float samples of the reference's input callback (dabsdr.h:387) to the GPU
+ * without touching them on the host: in_rate_hz = 2048000, src_fmt = DABX_FMT_F32, gain = a power of two. */
+DABX_API int64_t dabx_push_resampled_from(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain, int src_kind);
+/* Largest |I| or |Q| (int16 units, after the gain) the converters wrote into the stream's ring between the submission of the
+ * step before the last one and the submission of the last one; valid after dabx_wait.  (Input level for a caller's gain control.) */
+DABX_API int dabx_get_input_peak(dabx_ctx *ctx, int stream, int32_t *peak);
 /* Test/diagnostic accessor: copies n complex samples starting at absolute sample index `from` out of a stream's ring. */
 DABX_API int dabx_read_ring(dabx_ctx *ctx, int stream, int64_t from, int64_t n, void *dst);
 
@@ -193,6 +202,8 @@ DABX_API int dabx_viterbi(dabx_ctx *ctx, int kind, int option, int level, int kb
 DABX_API int dabx_enable_spectrum(dabx_ctx *ctx, int mask);
 DABX_API int dabx_get_spectrum(dabx_ctx *ctx, int stream, float *power);
 DABX_API int dabx_get_null_spectrum(dabx_ctx *ctx, int stream, float *power);
+/* the null-symbol spectrum of EVERY frame of the last step: power [n_frames][2048] (dabx_get_null_spectrum = the last one) */
+DABX_API int dabx_get_null_spectra(dabx_ctx *ctx, int stream, float *power);
 
 /* DAB+ audio super frames (ETSI TS 102 563): fire code synchronisation, RS(120,110) correction and access
  * unit CRCs on the GPU for the sub-channels flagged here (bit k of mask = k-th entry of the list given to
@@ -217,6 +228,10 @@ DABX_API int dabx_set_dabplus(dabx_ctx *ctx, int stream, uint64_t mask);
 DABX_API int dabx_get_superframes(dabx_ctx *ctx, int stream, int sub, dabx_superframe_t *recs, uint8_t *data, int max);
 /* running totals: super frames, AUs good, AUs bad, bytes corrected, code words uncorrectable, sync losses */
 DABX_API int dabx_get_superframe_stats(dabx_ctx *ctx, int stream, int sub, uint32_t stats[6]);
+/* pos[0]: valid logical frames (CIFs) of the sub-channel seen so far, the last step's included — record r of that step was
+ * completed by the frame with index r.first_frame + 4, and the step's last CIF has index pos[0] - 1; pos[1]: frames carried
+ * over (< 5) into the next step.  Lets a caller place the records of a multi-frame step in time. */
+DABX_API int dabx_get_superframe_pos(dabx_ctx *ctx, int stream, int sub, uint32_t pos[2]);
 
 /* Raw-file front end: the reference's RawFileInput accepts headerless `.raw` files and `.uff`
  * files whose first 2048 bytes hold a zero-padded XML description (reference:

@@ -27,13 +27,16 @@ def _inject(host, fibs):
 def test_two_ensembles_in_one_recording_raise_reset_new_eid():
     from legacy_host import NID, LegacyHost
     sub = [[0, 0, 3, 64]]
-    iq, _, _ = ob.tx_generate(seed=95, eid=0x1234, n_frames=20, subch=sub, delay=1500, snr_db=25.0, eid2_from=9)
+    iq, _, _ = ob.tx_generate(seed=95, eid=0x1234, n_frames=44, subch=sub, delay=1500, snr_db=25.0, eid2_from=9)
     host = LegacyHost(iq.astype(np.float32) - 128.0, gate_on_new_eid=True)     # the un-paced library waits for the host's restart
     try:
         host.tune()
         host.wait_for(lambda e: e["nid"] == NID["SYNC_STATUS"] and e.get("level") == 3)
         rst = host.wait_for(lambda e: e["nid"] == NID["RESET"] and e.get("flag") == 1)[0]
-        assert 9 * 196608 < rst["at"] <= 12 * 196608                  # two FIG 0/0 of the other ensemble, not before frame 9
+        # two FIG 0/0 of the other ensemble, not before frame 9.  With an input that is not paced the library decodes up to 8 frames
+        # per step while the callback fills the next 8 (dabsdr_shim.cpp: kMaxBatch), so the notification may trail the input
+        # position by two steps
+        assert 9 * 196608 < rst["at"] <= (12 + 16) * 196608
         host.L.dabsdrRequest_Tune(host.handle, 225648)                # what the host does on it: start(m_frequency)
         host.wait_for(lambda e: e["nid"] == NID["TUNE"] and e["at"] >= rst["at"])
         host.open_gate()
