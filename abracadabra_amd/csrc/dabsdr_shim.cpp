@@ -132,7 +132,6 @@ struct dabsdr_s {
     std::deque<StepResults> done;        // fetched, not yet turned into callbacks
     double pull_s = 0.096;               // running estimate of the time the input callback takes per frame
     int batch = 1;                       // frames per step: what arrives within 48 ms, at most kMaxBatch
-    int prev_bad = 0;                    // frames in a row without a phase reference symbol at the end of the last delivered step
     bool pipelined = false;              // the step runs while the next buffer is filled (input faster than ~10 x real time)
     uint64_t next_serial = 1;
     int64_t pushed = 0;                  // samples handed to the context since it was created
@@ -334,7 +333,7 @@ void handle_request(dabsdr_s *h, const Request &r)
             notify(h, DABSDR_NID_TUNE, DABSDR_NSTAT_SUCCESS, &f, 0);
         } else {
             h->frequency = r.a;
-            h->gain_set = false; h->locked_hint = false; h->prev_bad = 0;
+            h->gain_set = false; h->locked_hint = false;
             h->fill = 0; h->inflight = false; h->done.clear();
             h->pushed = 0; h->gain_epochs.clear();
             h->buf_busy[0] = h->buf_busy[1] = false;       // dabx_destroy drains the copy stream
@@ -879,16 +878,13 @@ void deliver(dabsdr_s *h)
     while (!h->done.empty()) {
         StepResults r = std::move(h->done.front());
         h->done.pop_front();
-        // the device reports the lock state at the end of a step; inside a step the same rule runs here (k_finish: a locked
-        // receiver stays locked until four frames in a row have come without a phase reference symbol)
-        int bad = h->prev_bad;
-        for (int f = 0; f < r.n_frames; ++f) {
-            bad = (r.rec[static_cast<size_t>(f)].flags & 1) ? 0 : bad + 1;
-            const bool locked = f == r.n_frames - 1 ? r.st.locked != 0 : (h->locked_hint && bad < 4);
-            deliver_frame(h, r, f, locked);
-        }
-        h->prev_bad = r.st.bad;
-        h->locked_hint = r.st.locked != 0;
+        // The sync level the host sees is the frame's own: a frame whose phase reference symbol was not found reports
+        // NO_SYNC (the reference: "brief SYNC 0" at the wrap of a looped file) although the receiver's
+        // flywheel keeps its timing for up to four such frames (k_finish) before it searches from scratch.
+        for (int f = 0; f < r.n_frames; ++f) deliver_frame(h, r, f, (r.rec[static_cast<size_t>(f)].flags & 1) != 0);
+        // whole frames are batched only while the receiver tracks without doubt (a missing PRS makes the next step look for the
+        // null symbol again, which needs a frame more in the ring: chunk by chunk gets there soonest)
+        h->locked_hint = r.st.locked != 0 && r.st.bad == 0;
         // gain hysteresis on the level the GPU saw (int16 units after the gain)
         if (r.peak > 30000) --h->gain_shift;
         else if (r.peak > 0 && r.peak < 256 && h->gain_shift < 40) ++h->gain_shift;

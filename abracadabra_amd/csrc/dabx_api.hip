@@ -289,7 +289,8 @@ int build_superframe_work(dabx_ctx *c)
 
 int64_t samples_needed(const StreamHost &s, int n_frames)
 {
-    return s.st.pos + static_cast<int64_t>(n_frames + (s.st.locked ? 0 : 1)) * dabx::kTF + 4096;
+    // (one frame more while searching for the null symbol: not locked, or locked with the last frame's PRS missing)
+    return s.st.pos + static_cast<int64_t>(n_frames + ((s.st.locked && s.st.bad == 0) ? 0 : 1)) * dabx::kTF + 4096;
 }
 
 bool valid_stream(const dabx_ctx *c, int s) { return c && s >= 0 && s < c->cfg.n_streams; }

@@ -30,6 +30,7 @@ constexpr float LOCK_THR = 48.0f;
 constexpr int EARLY_SPAN = 400;            // the first path may lead the strongest one by up to this many samples ...
 constexpr float EARLY_THR = 0.125f;        // ... if it carries at least this fraction of its power (-9 dB)
 constexpr int RESYNC_THR = 32;             // PRS further than this from where the window expected it: second pass
+constexpr int RELOCK_TOL = 512;            // a null symbol further than this from where the flywheel expects it is another frame phase
 constexpr int SLOPE_MAX = 60 << 16;        // sampling-clock tracker: |drift| <= 60 samples per frame (~300 ppm), Q16
 constexpr int SCO_MIN = 1 << 16;           // de-rotate the differential product from this drift on: 1 sample per frame = 5.1 ppm
 constexpr int TI_SEG = CIFBITS / 16;   // bytes per residue class in a residue-major MSC row
@@ -290,7 +291,10 @@ __global__ __launch_bounds__(256) void k_null_search(DevCtx C)
 {
     const int s = blockIdx.x, t = threadIdx.x;
     DevState &st = C.state[s];
-    if (st.locked) return;
+    // a locked stream whose last frame came without a phase reference symbol looks for the null symbol again (a recording that
+    // loops or was cut jumps to another frame phase; waiting for four bad frames first would lose them all)
+    const bool suspect = st.locked && st.bad > 0;
+    if (st.locked && !suspect) return;
     __shared__ uint64_t E[NS_BLOCKS + NS_WIN];
     __shared__ uint64_t redv[256];
     __shared__ int redi[256];
@@ -339,12 +343,22 @@ __global__ __launch_bounds__(256) void k_null_search(DevCtx C)
     if (t == 0) {
         // quietest window at least 2.5 dB below the average window; the null ends where two consecutive blocks rise
         // above the midpoint between the null's level and the average block energy
-        if (!(best * 16 * NS_BLOCKS < tot * NS_WIN * 9)) { st.acq_fail = 1; return; }
+        if (!(best * 16 * NS_BLOCKS < tot * NS_WIN * 9)) { if (!suspect) st.acq_fail = 1; return; }
         const uint64_t mid = best * NS_BLOCKS + tot * NS_WIN;
         int edge = bb + NS_WIN;
         for (int b = bb; b + 1 < NS_BLOCKS + NS_WIN; ++b)
             if (E[b] * 2 * NS_WIN * NS_BLOCKS > mid && E[b + 1] * 2 * NS_WIN * NS_BLOCKS > mid) { edge = b; break; }
-        st.pos = st.pos + 64 * (int64_t)edge - TNULL;
+        const int64_t ns = st.pos + 64 * (int64_t)edge - TNULL;
+        if (suspect) {
+            // where the null symbol is against where the flywheel expects it, to the nearest whole frame; within RELOCK_TOL the
+            // flywheel carries on, beyond it this is another frame phase: a new acquisition from there
+            int64_t d = (ns - st.pos) % TF;
+            if (d < 0) d += TF;
+            if (d >= TF / 2) d -= TF;
+            if (d <= RELOCK_TOL && d >= -RELOCK_TOL) return;
+            st.locked = 0;
+        }
+        st.pos = ns;
         st.cif = 0;
         st.acq_fail = 0;
     }
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
         DevSync r;
         r.t_sym0 = w0 + delta - BACKOFF;
         r.inc = inc;
-        r.flags = ((peak * 2048.0f >= LOCK_THR * total) ? 1 : 0) | (wide ? 2 : 0);
+        r.flags = ((total > 0.0f && peak * 2048.0f >= LOCK_THR * total) ? 1 : 0) | (wide ? 2 : 0);      // (silence is not a phase reference symbol)
         r.peak_idx = pidx; r.m_int = m_best;
         r.peak = peak; r.total = total;
         r.cp_re = cre; r.cp_im = cim;

@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--nsub", type=int, default=18, help="48-CU EEP 3-A sub-channels per ensemble (18 = all 864 CU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-fed (PCIe-inclusive) side measurement")
+    ap.add_argument("--no-legacy", action="store_true", help="skip the single-ensemble side measurement through the reference's 24-function API")
+    ap.add_argument("--legacy-frames", type=int, default=3000, help="frames timed by each leg of the legacy side measurement")
     ap.add_argument("--dabplus", action="store_true",
                     help="side measurement: every sub-channel carries DAB+ super frames and k_superframe decodes them "
                          "(period 20 frames = 16 super frames per sub-channel; not the headline workload)")
@@ -291,6 +293,22 @@ def pcie_leg(args, dev, streams, sub):
             "pageable_synchronous": run(False), "pinned_overlapped": run(True)}
 
 
+def legacy_leg(args):
+    """ONE ensemble through the reference's 24-function API (libdabsdr.so.4 drop-in), un-paced C host (tools/legacy_rate.c):
+    the shape of BASELINE configs[0] / [2].  Both legs must decode without a FIB error; the service leg without an AU CRC error."""
+    from tools import legacy_bench
+    try:
+        r = legacy_bench.run(frames=args.legacy_frames)
+    except Exception as e:                                    # noqa: BLE001 — reported in the line, and the run fails
+        return {"ok": False, "error": repr(e)}
+    fic, svc = r.get("fic_only", {}), r.get("one_service_48cu", {})
+    ok = (fic.get("rc") == 0 and svc.get("rc") == 0 and fic.get("fib_errors") == 0 and svc.get("fib_errors") == 0 and fic.get("sync_level") == 3
+          and svc.get("access_units", 0) > 0 and svc.get("au_crc_err") == 0 and svc.get("au_concealed") == 0)
+    return {"unit": "x real-time, one ensemble, un-paced float input callback (dabsdr.h:387), all notifications and audio callbacks delivered",
+            "fic_only": fic, "one_service_48cu": svc, "ok": bool(ok),
+            "reference_binary_one_cpu_thread": {"fic_only": "188-195", "one_service_48cu": "105-110", "source": "SURVEY.md §6 (measured by the survey session; not run here)"}}
+
+
 # ---------------------------------------------------------------------------------------------------- one rank
 def run_rank(args, engine_factory=None):
     """Body of one rank (the whole run when N = 1).  Returns the process exit code."""
@@ -372,6 +390,11 @@ def run_rank(args, engine_factory=None):
         engine.close()
         pcie = pcie_leg(args, dev, streams, sub)
 
+    legacy = None
+    if gpu and world == 1 and not args.no_legacy:
+        engine.close()
+        legacy = legacy_leg(args)
+
     elapsed, (ok, bad, mism, checked, n_streams) = reduce_over_ranks(dist, 2 if force_dist else world, red_device, elapsed, [ok, bad, mism, checked, S])
 
     rc = 0
@@ -390,7 +413,7 @@ def run_rank(args, engine_factory=None):
             return round(insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 4) if insts and ms > 0 else None
 
         out = {
-            "metric": "DAB Mode-I ensembles decoded x real-time per GPU (2048-FFT + de-interleave + Viterbi, full FIC+MSC)",
+            "metric": "DAB Mode-I ensembles decoded x real-time, all GPUs together (2048-FFT + de-interleave + Viterbi, full FIC+MSC); per GPU: x_realtime_per_gpu",
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 FFT / int8 soft bits / int32 path metrics", "data": "synthetic",
@@ -423,6 +446,11 @@ def run_rank(args, engine_factory=None):
             out["dabplus"] = dabplus
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if legacy is not None:
+            out["legacy_single_stream"] = legacy
+            if not legacy.get("ok"):
+                print(f"bench.py: FAILED legacy_single_stream: {legacy}", file=sys.stderr)
+                rc = 1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

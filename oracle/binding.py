@@ -161,6 +161,11 @@ class Stream:
         iq = np.ascontiguousarray(iq)
         self.L.orx_push(self.h, iq.ctypes.data, iq.size // 2)
 
+    def set_soft_bits(self, bits):
+        """test knob: 6 (the product's contract, +-31) or 8 (+-127) bit soft decisions"""
+        self.L.orx_set_soft_bits.argtypes = [C.c_void_p, C.c_int]
+        self.L.orx_set_soft_bits(self.h, int(bits))
+
     def set_write_pos(self, wr):
         """wr = 1 << 62: resident periodic ring that never underruns (as dabx_set_write_pos)"""
         self.L.orx_set_wr.argtypes = [C.c_void_p, C.c_int64]
@@ -218,10 +223,11 @@ def decode_linear(soft, kind=0, option=0, level=3, kbps=64):
     return out[:n].copy()
 
 
-def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0, au_heads=None):
+def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0, au_heads=None, equal_aus=False):
     """Random DAB+ audio super frames for a kbps sub-channel.
     au_heads: optional list of byte strings; access unit i starts with au_heads[i] (e.g. a data_stream_element
     carrying PAD), the rest of it is random.
+    equal_aus: access units of equal size (64 kbit/s, 3 units: 290 / 289 / 289 bytes — the sizes the survey's probe used).
     Returns (bytes [n_superframes*5, 3*kbps] = one row per logical frame, list of AU payloads)."""
     L = lib()
     s = kbps // 8
@@ -233,6 +239,8 @@ def superframes(kbps, n_superframes, seed=0, dac_rate=1, sbr=1, ch_mode=1, ps=0,
     aus = []
     for f in range(n_superframes):
         cuts = np.sort(rng.choice(np.arange(8, room - 8), num_aus - 1, replace=False)) if num_aus > 1 else np.array([], dtype=int)
+        if equal_aus:                                       # access units of (nearly) one size, the longer ones first
+            cuts = np.cumsum([room // num_aus + (1 if i < room % num_aus else 0) for i in range(num_aus - 1)])
         lens = np.diff(np.concatenate([[0], cuts, [room]])).astype(np.int32)
         while au_heads is not None and num_aus > 1 and lens.min() < 40:         # room for the prescribed heads
             cuts = np.sort(rng.choice(np.arange(8, room - 8), num_aus - 1, replace=False))

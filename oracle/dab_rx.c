@@ -239,6 +239,8 @@ typedef struct {
     uint32_t fic_stepinfo[DAB_FIC_CW_IN + 6];
     float spectrum[NFFT];       /* |FFT|^2 of the last frame's PRS window, natural bin order */
     float null_spectrum[NFFT];  /* same for 2048 samples centred in the null symbol */
+    int soft_extra;             /* 0: the product's six-bit soft decisions (+-31); 2: eight bits (+-127), for the sensitivity
+                                   comparison of tests/test_msc_sensitivity.py only */
 } orx_t;
 
 typedef struct {                /* per-frame synchronisation record (same layout as dabx_sync_rec) */
@@ -300,6 +302,8 @@ void orx_push(orx_t *s, const void *iq, int64_t n)
 }
 /* resident periodic ring (benchmarks): wr = 2^62 means "never underruns, never overruns", as dabx_set_write_pos */
 void orx_set_wr(orx_t *s, int64_t wr) { s->wr = wr; }
+/* test knob: soft decisions of 6 (the contract, default) or 8 bits */
+void orx_set_soft_bits(orx_t *s, int bits) { s->soft_extra = bits == 8 ? 2 : 0; }
 void orx_get_spectrum(const orx_t *s, float *out) { memcpy(out, s->spectrum, sizeof s->spectrum); }
 void orx_get_null_spectrum(const orx_t *s, float *out) { memcpy(out, s->null_spectrum, sizeof s->null_spectrum); }
 void orx_get_state(const orx_t *s, int64_t *st)
@@ -378,6 +382,7 @@ static void sync_pass(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx
  * from where the window expected it (acquisition of a recording with a sampling-clock error, several frames per step),
  * a second pass at the corrected position, so that the guard-interval correlation looks at guard intervals. */
 #define RESYNC_THR 32
+#define RELOCK_TOL 512      /* a null symbol further than this from where the flywheel expects it is another frame phase */
 static void sync_frame(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx_sync_t *rec, float *spectrum, float *null_spectrum)
 {
     sync_pass(s, pos_f, inc0, wide, rec, spectrum, null_spectrum);
@@ -487,7 +492,7 @@ static void sync_pass(const orx_t *s, int64_t pos_f, int32_t inc0, int wide, orx
     int delta = pidx >= 1024 ? pidx - 2048 : pidx;
     rec->t_sym0 = w0 + delta - BACKOFF;
     rec->inc = inc;
-    rec->flags = ((peak * 2048.0f >= LOCK_THR * total) ? 1 : 0) | (wide ? 2 : 0);
+    rec->flags = ((total > 0.0f && peak * 2048.0f >= LOCK_THR * total) ? 1 : 0) | (wide ? 2 : 0);   /* (silence is not a phase reference symbol) */
     rec->peak_idx = pidx; rec->m_int = m_best;
     rec->peak = peak; rec->total = total;
     rec->cp_re = cre; rec->cp_im = cim;
@@ -545,7 +550,8 @@ static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *f
                 part[t] = acc;
             }
             float S = reduce256(part), g = 0.0f;
-            if (S > 0.0f && S < INFINITY) { int E; frexpf(S, &E); g = ldexpf(1.0f, SOFT_EXP - E); }
+            if (S > 0.0f && S < INFINITY) { int E; frexpf(S, &E); g = ldexpf(1.0f, SOFT_EXP + s->soft_extra - E); }
+            const float smax = s->soft_extra ? 127.0f : SOFT_MAX;
             int8_t *dst;
             if (l <= DAB_FIC_SYMS) dst = fic + (l - 1) * DAB_SYM_BITS;
             else dst = s->ti + (size_t)((cif0 + (l - 4) / DAB_CIF_SYMS) & (s->ti_slots - 1)) * DAB_CIF_BITS + ((l - 4) % DAB_CIF_SYMS) * DAB_SYM_BITS;
@@ -553,8 +559,8 @@ static void demod_frame(orx_t *s, const orx_sync_t *rec, int64_t cif0, int8_t *f
                 int n = T.n_of_bin[T.bin_of_pos[p]];
                 if (n < 0) continue;
                 float a = rintf(yr[p] * g), b = rintf(yi[p] * g);
-                a = a > SOFT_MAX ? SOFT_MAX : (a < -SOFT_MAX ? -SOFT_MAX : a);
-                b = b > SOFT_MAX ? SOFT_MAX : (b < -SOFT_MAX ? -SOFT_MAX : b);
+                a = a > smax ? smax : (a < -smax ? -smax : a);
+                b = b > smax ? smax : (b < -smax ? -smax : b);
                 dst[n] = (int8_t)a; dst[n + DAB_K] = (int8_t)b;
             }
         }
@@ -700,11 +706,28 @@ int orx_process(orx_t *s, int n_frames, orx_sync_t *sync, int8_t *fic_soft, int8
                 uint8_t *fib, uint8_t *fib_ok, uint8_t *msc, uint8_t *msc_valid)
 {
     int wide = !s->locked;
-    int64_t need = s->pos + (int64_t)(n_frames + (wide ? 1 : 0)) * DAB_TF + 4096;
+    /* a locked receiver whose last frame came without a phase reference symbol looks for the null symbol again before it
+     * goes on (one more frame of samples, like an acquisition): a recording that loops or was cut jumps to another frame
+     * phase, and waiting for four bad frames before searching would lose them all (the reference loses one frame at the
+     * wrap of a looped file: SURVEY.md App. A.3) */
+    const int suspect = s->locked && s->bad > 0;
+    int64_t need = s->pos + (int64_t)(n_frames + ((wide || suspect) ? 1 : 0)) * DAB_TF + 4096;
     if (need > s->wr) return -1;
     if (15 + 4 * n_frames > s->ti_slots) return -3;
     if (s->wr < ((int64_t)1 << 62) && s->wr - s->pos > s->ring_len) return -2;
-    if (wide) {
+    if (suspect) {
+        int64_t ns;
+        if (null_search(s, s->pos, &ns)) {
+            /* where the null symbol is against where the flywheel expects it, to the nearest whole frame */
+            int64_t d = (ns - s->pos) % DAB_TF;
+            if (d < 0) d += DAB_TF;
+            if (d >= DAB_TF / 2) d -= DAB_TF;
+            if (d > RELOCK_TOL || d < -RELOCK_TOL) {        /* another frame phase: a new acquisition from there */
+                s->pos = ns; s->cif = 0; s->locked = 0;
+                wide = 1;
+            }
+        }
+    } else if (wide) {
         int64_t ns;
         if (!null_search(s, s->pos, &ns)) {
             s->pos += (int64_t)n_frames * DAB_TF;

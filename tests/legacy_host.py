@@ -13,9 +13,12 @@ TF = 196608
 
 
 class LegacyHost:
-    def __init__(self, samples_f32, gate_at=None, gate_on_new_eid=False):
+    def __init__(self, samples_f32, gate_at=None, gate_on_new_eid=False, pace=0.0):
         """samples_f32: interleaved I,Q floats the input callback hands out (zeros after the end, like a flushed FIFO).
-        gate_at: sample count (complex) after which the input blocks until open_gate() (the library is un-paced)."""
+        gate_at: sample count (complex) after which the input blocks until open_gate() (the library is un-paced).
+        pace: seconds every input call takes at least — 0.0025 (30 ms per frame) makes the library decode frame by frame and
+        deliver at once, as it does behind the reference's raw-file input, which a 50 ms timer paces (rawfileinput.cpp:236-238)."""
+        self.pace = pace
         self.L = aa.load_library()
         self.samples = np.ascontiguousarray(samples_f32, dtype=np.float32)
         self.pos = 0
@@ -30,6 +33,8 @@ class LegacyHost:
         def get_samples(buf, n):
             if self.gate_at is not None and self.pos >= 2 * self.gate_at and not self.gate.is_set():
                 self.gate.wait(0.05)
+            if self.pace:
+                time.sleep(self.pace)
             out = np.ctypeslib.as_array(buf, shape=(2 * n,))
             take = self.samples[self.pos:self.pos + 2 * n]
             out[:len(take)] = take
@@ -54,7 +59,8 @@ class LegacyHost:
                 rec.update(ueid=e.ueid, lto=e.LTO, label=e.label.str.decode(), charField=e.label.charField, freq=e.frequency)
             elif n.nid == NID["PERIODIC"] and n.pData:
                 pr = C.cast(n.pData, C.POINTER(Periodic)).contents
-                rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel, snr10=pr.snr10)
+                rec.update(fib_err=pr.fibErrorCntr, foff=pr.freqOffset, level=pr.syncLevel, snr10=pr.snr10, crc_ok=pr.mscCrcOkCntr,
+                           crc_err=pr.mscCrcErrorCntr, rs_unc=pr.rsUncorrectableCntr, audio_bytes=pr.audioServiceBytes)
             elif n.nid == NID["SERVICE_LIST"]:
                 sl = C.cast(n.pData, C.POINTER(ServiceList)).contents
                 items = []
@@ -92,13 +98,14 @@ class LegacyHost:
         class DlCB(C.Structure):                      # dabsdrDynamicLabelCBData_t (dabsdr.h:81-86)
             _fields_ = [("id", C.c_int), ("len", C.c_uint16), ("pData", C.POINTER(C.c_uint8))]
 
-        self.audio, self.labels = [], []
+        self.audio, self.labels, self.audio_at = [], [], []
 
         @C.CFUNCTYPE(None, C.POINTER(AudioCB), C.c_void_p)
         def on_audio(p, ctx):
             a = p.contents
             with self.lock:
                 self.audio.append((a.id, a.ASCTy, a.header, bytes(np.ctypeslib.as_array(a.pAuData, shape=(a.auLen,)))))
+                self.audio_at.append(self.pos // 2)
 
         @C.CFUNCTYPE(None, C.POINTER(DlCB), C.c_void_p)
         def on_dl(p, ctx):
@@ -134,8 +141,9 @@ class LegacyHost:
         L.dabsdrRequest_ServiceSelection.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8, C.c_int]
         L.dabsdr(self.handle)
 
-    def tune(self, khz=225648, periodic=0):
-        self.L.dabsdrRequest_SetPeriodicNotify(self.handle, 1, periodic)
+    def tune(self, khz=225648, periodic=0, period_log2=1):
+        """period_log2: periodic notification every 2^n frames (the reference's host asks for 3: radiocontrol.h:43-46)"""
+        self.L.dabsdrRequest_SetPeriodicNotify(self.handle, period_log2, periodic)
         self.L.dabsdrRequest_Tune(self.handle, khz)
 
     def open_gate(self):

@@ -97,7 +97,7 @@ def test_bench_collectives_run_over_rccl_on_this_gpu():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_FORCE_DIST="1",
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--streams", "8", "--steps", "2", "--warmup", "3",
-                          "--no-cpu-baseline", "--no-pcie"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                          "--no-cpu-baseline", "--no-pcie", "--no-legacy"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["collective"] == "nccl" and d["n_gpus"] == 1 and d["fib_crc_bad"] == 0 and d["fib_crc_ok"] == 8 * 8 * 12
@@ -112,3 +112,9 @@ def test_bench_line_contract_single_gpu():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and c["fic_only"]["value"] > c["value"]
+    # the drop-in 24-function library with ONE ensemble and an un-paced C host (tools/legacy_rate.c), both legs error free and
+    # faster than the reference's binary on one CPU thread (188-195 x FIC-only, 105-110 x with one 48-CU service)
+    g = d["legacy_single_stream"]
+    assert g["ok"], g
+    assert g["fic_only"]["fib_errors"] == 0 and g["fic_only"]["x_realtime"] > 195
+    assert g["one_service_48cu"]["au_crc_err"] == 0 and g["one_service_48cu"]["access_units"] > 1000 and g["one_service_48cu"]["x_realtime"] > 110
