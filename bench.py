@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--nsub", type=int, default=18, help="48-CU EEP 3-A sub-channels per ensemble (18 = all 864 CU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-fed (PCIe-inclusive) side measurement")
+    ap.add_argument("--pcie-all-ranks", action="store_true",
+                    help="N > 1: every rank runs the host-fed side measurement at the same time (shows the host-ingest limit of the node)")
     ap.add_argument("--no-legacy", action="store_true", help="skip the single-ensemble side measurement through the reference's 24-function API")
     ap.add_argument("--legacy-frames", type=int, default=3000, help="frames timed by each leg of the legacy side measurement")
     ap.add_argument("--dabplus", action="store_true",
@@ -188,6 +190,17 @@ def reduce_over_ranks(dist, world, device, elapsed, counters):
     return float(tmax[0]), [int(round(float(x))) for x in t[1:]]
 
 
+def gather_floats(dist, world, device, x):
+    """one float per rank on every rank (diagnostics of the line: a slow rank shows)"""
+    if dist is None or world == 1:
+        return [round(float(x), 3)]
+    import torch
+    mine = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [round(float(t[0]), 3) for t in out]
+
+
 def profile_counters(S, F, kernel="k_viterbi"):
     """Per-launch PMC figures of `kernel` from the committed rocprofv3 passes of this workload
     (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py from the same bench command under
@@ -293,6 +306,29 @@ def pcie_leg(args, dev, streams, sub):
             "pageable_synchronous": run(False), "pinned_overlapped": run(True)}
 
 
+def pin_to_gpu_numa_node(torch, dev):
+    """N > 1: run this rank on the cores of its GPU's NUMA node, so that its page-locked staging buffers (first touch) and the
+    threads that fill them sit next to the PCIe root the GPU hangs on (host ingest is the limit of a host-fed
+    multi-GPU run).  Returns the node number, or None when the topology cannot be read (then nothing is changed)."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:                                         # noqa: BLE001 — a missing sysfs entry must not stop the run
+        return None
+
+
 def legacy_leg(args):
     """ONE ensemble through the reference's 24-function API (libdabsdr.so.4 drop-in), un-paced C host (tools/legacy_rate.c):
     the shape of BASELINE configs[0] / [2].  Both legs must decode without a FIB error; the service leg without an AU CRC error."""
@@ -346,8 +382,12 @@ def run_rank(args, engine_factory=None):
     assert P % 4 == 0 and P >= F + 2
 
     gids = stream_ids(rank, S)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    numa = pin_to_gpu_numa_node(torch, dev) if (gpu and world > 1 and args.force_device < 0) else None
+    # the ranks of one node share its cores: each takes its share for the synthesis (and for the staging copies of --pcie)
+    workers = max(1, min(16, len(os.sched_getaffinity(0)) // (1 if numa is not None else max(1, local_world))))
     t_gen = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as ex:
+    with ThreadPoolExecutor(max_workers=workers) as ex:
         streams = list(ex.map(lambda g: make_stream(args, g, sub), gids))
     t_gen = time.perf_counter() - t_gen
 
@@ -385,9 +425,17 @@ def run_rank(args, engine_factory=None):
         dabplus = {"stats_of_sampled_subchannels": tot, "post_viterbi_ms_per_step": round(float(phase_ms[3]) / args.steps, 3),
                    "superframes_per_step": S * len(sub) * 4 * F // 5}
 
+    # every rank proves its own work before anything is reduced: a rank that decoded nothing cannot hide in a sum
+    rank_ok = (ok + bad == S * F * 12) and bad == 0 and mism == 0 and checked >= S * F
+    if not rank_ok:
+        print(f"bench.py: rank {rank}: FAILED correctness: fib_crc_ok={ok} fib_crc_bad={bad} payload_checked={checked} payload_mismatch={mism}",
+              file=sys.stderr, flush=True)
+
     pcie = None
-    if gpu and world == 1 and not args.no_pcie:
+    if gpu and not args.no_pcie and (world == 1 or args.pcie_all_ranks):
         engine.close()
+        if dist is not None:
+            dist.barrier()                       # all ranks pull from the host at the same time: that is the point
         pcie = pcie_leg(args, dev, streams, sub)
 
     legacy = None
@@ -395,9 +443,13 @@ def run_rank(args, engine_factory=None):
         engine.close()
         legacy = legacy_leg(args)
 
-    elapsed, (ok, bad, mism, checked, n_streams) = reduce_over_ranks(dist, 2 if force_dist else world, red_device, elapsed, [ok, bad, mism, checked, S])
+    my_elapsed = elapsed
+    pcie_v = pcie["pinned_overlapped"]["value"] if pcie else 0.0
+    elapsed, (ok, bad, mism, checked, n_streams, ranks_ok, pcie_sum) = reduce_over_ranks(
+        dist, 2 if force_dist else world, red_device, elapsed, [ok, bad, mism, checked, S, int(rank_ok), pcie_v])
+    per_rank_ms = gather_floats(dist, world, red_device, my_elapsed / args.steps * 1e3)
 
-    rc = 0
+    rc = 0 if rank_ok else 1
     if rank == 0:
         frames_total = n_streams * F * args.steps
         value = frames_total * FRAME_S / elapsed
@@ -444,8 +496,18 @@ def run_rank(args, engine_factory=None):
         }
         if args.dabplus:
             out["dabplus"] = dabplus
+        out["ranks_ok"] = ranks_ok
+        out["ms_per_step_by_rank"] = per_rank_ms
+        out["setup_s"]["synthesis_threads"] = workers
+        if numa is not None:
+            out["setup_s"]["numa_node_of_rank0"] = numa
+        if ranks_ok != (2 if force_dist else world):
+            print(f"bench.py: FAILED: only {ranks_ok} of {world} ranks verified their own output", file=sys.stderr)
+            rc = 1
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+            if world > 1:
+                out["pcie_inclusive"]["all_ranks_pinned_overlapped_sum"] = round(pcie_sum, 1)
         if legacy is not None:
             out["legacy_single_stream"] = legacy
             if not legacy.get("ok"):

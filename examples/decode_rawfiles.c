@@ -46,6 +46,9 @@ int main(int argc, char **argv)
     if (!stage) { fprintf(stderr, "no pinned memory\n"); return 1; }
     int64_t want = chunk + DABX_FRAME_SAMPLES + 4096;      /* acquisition needs one frame more */
     long steps = 0;
+    long *fib_good = calloc((size_t)S, sizeof *fib_good), *fib_bad = calloc((size_t)S, sizeof *fib_bad);
+    int *eid = calloc((size_t)S, sizeof *eid);
+    for (int s = 0; s < S; s++) eid[s] = -1;
     for (;;) {
         int64_t got = want;
         for (int s = 0; s < S; s++) {
@@ -60,6 +63,16 @@ int main(int argc, char **argv)
             rc = dabx_process(ctx, nf);                   /* also waits for the copy above: the staging buffer is free again */
             if (rc) { fprintf(stderr, "dabx_process: %s\n", dabx_strerror(rc)); break; }
             ++steps;
+            for (int s = 0; s < S; s++) {                 /* what the FIC said in this step */
+                static uint8_t fib[FRAMES_PER_STEP * DABX_FIBS_PER_FRAME * DABX_FIB_BYTES], ok[FRAMES_PER_STEP * DABX_FIBS_PER_FRAME];
+                if (dabx_get_fib(ctx, s, fib, ok)) continue;
+                for (int k = 0; k < nf * DABX_FIBS_PER_FRAME; k++) {
+                    if (!ok[k]) { ++fib_bad[s]; continue; }
+                    ++fib_good[s];
+                    const uint8_t *b = fib + k * DABX_FIB_BYTES;
+                    if (eid[s] < 0 && b[0] == 0x05 && (b[1] & 0x1F) == 0) eid[s] = (b[2] << 8) | b[3];    /* FIG 0/0: ensemble identifier */
+                }
+            }
         } else if (got < want) break;
         want = chunk;
     }
@@ -69,12 +82,12 @@ int main(int argc, char **argv)
     for (int s = 0; s < S; s++) {
         dabx_stream_state_t st;
         dabx_get_state(ctx, s, &st);
-        printf("  %s: %s, carrier offset %.1f Hz, %lld CIFs\n", argv[s + 1], st.locked ? "locked" : "no DAB signal",
-               (double)st.inc * 2048000.0 / 4294967296.0, (long long)st.cif);
+        printf("  %s: %s, carrier offset %.1f Hz, %lld CIFs, FIBs %ld good %ld bad, EId %04X\n", argv[s + 1], st.locked ? "locked" : "no DAB signal",
+               (double)st.inc * 2048000.0 / 4294967296.0, (long long)st.cif, fib_good[s], fib_bad[s], eid[s] & 0xFFFF);
         fclose(f[s]);
     }
     dabx_free_pinned(stage);
     dabx_destroy(ctx);
-    free(f);
+    free(f); free(fib_good); free(fib_bad); free(eid);
     return 0;
 }

@@ -87,6 +87,23 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["config"]["streams_per_gpu"] == 8 and d["scaling"] == "weak"
 
 
+def test_bench_two_ranks_over_rccl_on_one_gpu_is_refused_by_rccl():
+    """the N > 1 RCCL path with two REAL ranks needs two GPUs: RCCL (like NCCL) refuses a communicator whose ranks share a
+    device.  What happens on this one-GPU box is recorded here so that nobody has to guess: either the run works (a runtime
+    that allows it) and must then be correct, or it fails at communicator set-up — never with a wrong result."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--backend", "nccl",
+                          "--streams", "8", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-legacy"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode == 0:
+        d = json.loads(lines[-1])
+        assert d["n_gpus"] == 2 and d["collective"] == "nccl" and d["fib_crc_bad"] == 0 and d["ranks_ok"] == 2
+    else:
+        assert not lines, "a failed run must not print a result line"
+        text = (out.stderr + out.stdout).lower()
+        assert "duplicate gpu" in text or "invalid usage" in text or "nccl" in text, text[-2000:]
+
+
 def test_bench_collectives_run_over_rccl_on_this_gpu():
     """one rank, but with the process group and the collectives of the N > 1 path (BENCH_FORCE_DIST): init_process_group("nccl",
     device_id), barrier and all_reduce of device tensors execute over RCCL on the test box's GPU"""
