@@ -501,7 +501,7 @@ def run_rank(args, engine_factory=None):
         out["setup_s"]["synthesis_threads"] = workers
         if numa is not None:
             out["setup_s"]["numa_node_of_rank0"] = numa
-        if ranks_ok != (2 if force_dist else world):
+        if ranks_ok != world:
             print(f"bench.py: FAILED: only {ranks_ok} of {world} ranks verified their own output", file=sys.stderr)
             rc = 1
         if pcie is not None:
