@@ -80,7 +80,9 @@ struct dabx_ctx {
     uint8_t *d_fib = nullptr, *d_fib_ok = nullptr, *d_msc = nullptr, *d_msc_valid = nullptr;
     DevSub *d_sub = nullptr;
     uint32_t *d_info = nullptr;
-    uint32_t *d_prbs = nullptr, *d_scratch = nullptr;
+    uint32_t *d_prbs = nullptr, *d_scratch = nullptr, *d_requeue = nullptr;
+    uint32_t rq_words_per_wave = 0;
+    size_t work_cap_rq = 0;                 // entries the requeue list holds (its running total sits behind them)
     DevWork *d_work = nullptr;
     float2 *d_W = nullptr, *d_nhi = nullptr, *d_nlo = nullptr;
     int16_t *d_bop = nullptr, *d_nob = nullptr, *d_car = nullptr;
@@ -134,10 +136,10 @@ struct dabx_ctx {
         c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car, d_cordic};
         c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
         c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
-        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
+        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.requeue = d_requeue; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
         c.ring_len = cfg.ring_samples; c.ring_bytes = stride();
         c.n_streams = cfg.n_streams; c.max_frames = cfg.max_frames; c.ti_slots = ti_slots;
-        c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0;
+        c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0; c.requeue_cap = static_cast<int32_t>(work_cap_rq);
         return c;
     }
 
@@ -204,19 +206,27 @@ int build_work(dabx_ctx *c, int n_frames)
                                    static_cast<uint32_t>(sh.prof[k].steps())});
         }
     std::stable_sort(all.begin(), all.end(), [](const DevWork &a, const DevWork &b) { return a.nsteps > b.nsteps; });
-    size_t blocks = 0;                                  // in units of 64 words = one decision word (24 steps) per lane
-    for (auto &w : all) {
-        w.scratch = static_cast<uint32_t>(blocks);
-        blocks += w.nsteps / 24 + 1;
-    }
-    if (blocks >> 32) return DABX_E_NOMEM;
+    // scratch for the codewords whose survivors do not merge (k_viterbi_requeue): one block per WAVE of that kernel, sized for
+    // the longest codeword — 64 words per 24 steps.  (Until round 3 every codeword had its own block: 2.5 GB for the benchmark's
+    // 155 648 codewords per step, none of it ever touched.)
+    const size_t words_per_wave = all.empty() ? 0 : (static_cast<size_t>(all.front().nsteps) / 24 + 1) * 64;
+    const size_t blocks = words_per_wave / 64 * VIT_RQ_BLOCKS * 4;
     c->n_work = static_cast<int>(all.size());
     if (all.size() > c->work_cap) {                      // grows only: the one-frame legacy path alternates between sizes
         if (c->d_work) (void)hipFree(c->d_work);
         c->d_work = nullptr; c->work_cap = 0;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_work), all.size() * sizeof(DevWork)));
+        uint32_t total = 0;                              // the running total moves with the list
+        if (c->d_requeue) HIPCHK(hipMemcpy(&total, c->d_requeue + 1 + c->work_cap_rq, sizeof total, hipMemcpyDeviceToHost));
+        if (c->d_requeue) (void)hipFree(c->d_requeue);
+        c->d_requeue = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_requeue), (all.size() + 2) * sizeof(uint32_t)));
+        HIPCHK(hipMemset(c->d_requeue, 0, sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(c->d_requeue + 1 + all.size(), &total, sizeof total, hipMemcpyHostToDevice));
+        c->work_cap_rq = all.size();
         c->work_cap = all.size();
     }
+    c->rq_words_per_wave = static_cast<uint32_t>(words_per_wave);
     if (!all.empty()) HIPCHK(hipMemcpy(c->d_work, all.data(), all.size() * sizeof(DevWork), hipMemcpyHostToDevice));
     if (blocks * 64 > c->scratch_words) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -397,7 +407,7 @@ void dabx_destroy(dabx_ctx *c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
-                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_requeue, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic, c->d_rs_state, c->d_rs_in, c->d_rs_mu, c->d_rs_seg, c->d_rs_A, c->d_rs_x};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -774,7 +784,10 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
         if (any_sco) hipLaunchKernelGGL((k_demod<1, true>), dim3(S * n_frames * DEMOD_GROUPS), dim3(256), 0, q, d, n_frames);
     }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
-    if (c->n_work) hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
+    if (c->n_work) {
+        hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
+        hipLaunchKernelGGL(k_viterbi_requeue, dim3(VIT_RQ_BLOCKS), dim3(256), 0, q, d, c->d_work, c->rq_words_per_wave);
+    }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[5], q));
     if (!c->sf_subs.empty())
         hipLaunchKernelGGL(k_superframe, dim3(static_cast<unsigned>(c->sf_subs.size())), dim3(SF_THREADS), 0, q, d, c->d_sf_subs, c->d_sf_state,
@@ -1082,6 +1095,18 @@ int dabx_rawfile_probe(const uint8_t *head, int n_bytes, dabx_rawfile_info_t *in
     if (!head || n_bytes < 0 || !info) return DABX_E_ARG;
     const rawfile::Info r = rawfile::probe(head, n_bytes);
     *info = {r.has_header, r.fmt, r.data_offset, r.channel_count, r.samplerate, r.frequency_khz};
+    return DABX_OK;
+}
+
+int dabx_get_requeue_total(dabx_ctx *c, uint64_t *total)
+{
+    if (!c || !total) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    if (c->pending) return DABX_E_ARG;
+    uint32_t t = 0;
+    if (c->d_requeue) HIPCHK(hipMemcpy(&t, c->d_requeue + 1 + c->work_cap_rq, sizeof t, hipMemcpyDeviceToHost));
+    *total = t;
     return DABX_OK;
 }
 

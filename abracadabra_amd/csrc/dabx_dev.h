@@ -41,7 +41,7 @@ struct DevWork {        // one Viterbi codeword = one wave
     int16_t frame;
     int8_t c;           // FIC codeword 0..3 or CIF 0..3
     int8_t sub;         // -1 = FIC
-    uint32_t scratch;   // the codeword's block of dec_scratch, in units of 64 words (= the decision word of every lane for 24 steps)
+    uint32_t scratch;   // (unused since round 3: scratch belongs to the waves of k_viterbi_requeue, not to codewords)
     uint32_t nsteps;
 };
 
@@ -102,10 +102,12 @@ struct DevCtx {
     const DevSub *sub;          // [S][64]
     const uint32_t *stepinfo;   // pooled depuncturing maps
     const uint32_t *prbs;       // energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
-    uint32_t *dec_scratch;      // decision words of k_viterbi: 64 words per 24 trellis steps and codeword (fallback, see k_viterbi)
+    uint32_t *dec_scratch;      // k_viterbi_requeue: per wave the decision words of one codeword, 64 words per 24 trellis steps
+    uint32_t *requeue;          // [0] number of codewords k_viterbi gave up on (survivors did not merge), [1..cap] their work
+                                // indices, [1 + cap] running total over the steps
     float *spectrum;            // [S][2048] |FFT|^2 of the last frame's PRS window, natural bin order; may be null
     float *null_spectrum;       // [S][F][2048] same for 2048 samples in the middle of every frame's null symbol (noise level, TII); may be null
     int64_t ring_len;           // samples
     size_t ring_bytes;          // bytes per stream
-    int32_t n_streams, max_frames, ti_slots, msc_stride, fic_info_off;
+    int32_t n_streams, max_frames, ti_slots, msc_stride, fic_info_off, requeue_cap;
 };

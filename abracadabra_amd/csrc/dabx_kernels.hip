@@ -9,7 +9,9 @@
 //   k_demod        2048-point FFT, pi/4-DQPSK demap, frequency de-interleave -> int8
 //   k_viterbi      time de-interleave gather, depuncture, K=7 Viterbi, de-dispersal
 //   k_finish       FIB CRC-16 and per-stream tracking state
-// No MFMA: the FFT is LDS-exchange bound, the Viterbi is VALU/DPP bound.
+// No MFMA GEMM anywhere (nothing here is a contraction): the FFT is bound by its LDS exchanges, the Viterbi by VALU
+// issue.  The matrix core appears once, as a sign-combination engine: six v_mfma_i32_4x4x4_16b_i8 per 24 trellis steps
+// form the branch metrics of k_viterbi so that the vector ALU is left with three instructions per step.
 //
 // Arithmetic contract: every float operation below is one IEEE
 // binary32 operation in a fixed order — a fused multiply-add only where it is
@@ -611,6 +613,10 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     __shared__ float2 twl[TWL];
     cf twa[7];
     load_twiddles_lds(twa, twl, T.W, t);
+#ifdef DABX_PROBE_STAGGER
+    // timing probe: workgroups in odd slots of their CU (HW_ID.TG_ID) start late, so that their LDS phases meet the others' VALU phases
+    if ((__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 1)) __builtin_amdgcn_s_sleep(DABX_PROBE_STAGGER);
+#endif
     // where the soft-bit pair of each FFT output position goes in the staging buffer: the frequency de-interleaver index n
     // itself for FIC symbols ([0]), its residue-major place (n & 15) * 96 + (n >> 4) for MSC symbols ([1]); the bins
     // outside the 1536 carriers go to a dummy slot of the lane (no branch around the store), used[] masks them out of the sum
@@ -721,8 +727,10 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 // One wave per codeword, one trellis state per lane.  The lane<->state map
 // rotates every step so that the two candidates of a butterfly always sit in
 // lanes that differ by one fixed xor vector of the cycle {1,2,7,8,16,32}:
-// four of the six exchanges are single DPP moves, two go through the LDS
-// crossbar (ds_swizzle / ds_bpermute), none touches LDS memory.
+// four of the six exchanges are a DPP modifier of the max, two go through the LDS
+// crossbar (ds_swizzle / ds_bpermute).  LDS MEMORY holds what is not exchanged: the
+// block's soft values (the A rows of the MFMAs), the 19-entry address table of the
+// gather and the ring of decision words the merge test and the traceback walk.
 namespace {
 
 // (the xor vectors of the six phases: 1, 2, 7, 8, 16, 32 — quad_perm, quad_perm, row_half_mirror, row_ror:8 as DPP
@@ -929,7 +937,10 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
 //   xs:     the wave's soft-value staging buffer in LDS: the A rows of a block's 48 steps at dword 0 (64 written), the 19
 //           dwords of the address table at 64
-__device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
+//   SPILL:  false = the first pass (k_viterbi): a codeword whose survivors do not merge gives up (returns false, dec is not
+//           touched) and is decoded again by k_viterbi_requeue, which has a block of scratch per wave (SPILL = true)
+template <bool SPILL>
+__device__ bool viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
     const int lane = threadIdx.x & 63;
@@ -998,6 +1009,7 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
                 trace_words(ring, dec, w_ring, w_dec, B, O, out32, prbs32, lane);
                 w_dec = w_ring = B;
             } else if (pend == VIT_RING) {                       // no merge and the ring is full: the unit goes to global scratch
+                if (!SPILL) return false;
 #pragma unroll
                 for (int k = 0; k < VIT_UNIT; ++k) dec[(w_ring + k) * 64 + lane] = ring[((w_ring + k) & (VIT_RING - 1)) * 64 + lane];
                 w_ring = B;
@@ -1007,14 +1019,34 @@ __device__ void viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
 #ifndef DABX_PROBE_NOTRACE
     trace_words(ring, dec, w_ring, w_dec, 2 * nblk, A, out32, prbs32, lane);
 #endif
+    return true;
 }
 
 }  // namespace
 
 // One wave per codeword (work item): FIC codeword c (0..3) of (stream, frame) when sub < 0, else MSC
 // sub-channel `sub` of CIF c.  Decisions live in a 4 KB ring of LDS per wave (eight waves per SIMD stay resident)
-// and are decoded as soon as the survivors have merged; the item's block of dec_scratch in global memory is the
-// fallback for input whose survivors do not merge.
+// and are decoded as soon as the survivors have merged.  A codeword whose survivors do not merge within 192 steps (erased or
+// tied input: silence, a punctured-out stretch) is put on the requeue list; k_viterbi_requeue decodes those again with a
+// block of global scratch per wave, so no scratch has to be held for the 155 000 codewords of a step that never need it.
+template <bool SPILL>
+__device__ __forceinline__ bool viterbi_item(const DevCtx &C, const DevWork &w, uint32_t *dec, int *xs, uint32_t *ring)
+{
+    const DevState &st = C.state[w.stream];
+    if (st.acq_fail) return true;
+    if (w.sub < 0) {
+        VitSrc src = {C.fic_soft + ((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304, 0, -1};
+        uint8_t *out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
+        return viterbi_wave<SPILL>(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out, xs, ring);
+    }
+    const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
+    const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
+    if (r < 0) return true;                          // time de-interleaver still filling (k_finish flags it)
+    VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + (sc.start_bit >> 4), r, C.ti_slots - 1};
+    uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
+    return viterbi_wave<SPILL>(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out, xs, ring);
+}
+
 __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__restrict__ work, int n_work)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
@@ -1022,24 +1054,23 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     if (wi >= n_work) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][84];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
-    int *xs = xs_all[wave];
-    uint32_t *ring = ring_all[wave];
-    const DevWork w = work[wi];
-    const DevState &st = C.state[w.stream];
-    if (st.acq_fail) return;
-    uint32_t *dec = C.dec_scratch + (size_t)w.scratch * 64;
-    if (w.sub < 0) {
-        VitSrc src = {C.fic_soft + ((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304, 0, -1};
-        uint8_t *out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
-        viterbi_wave(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out, xs, ring);
-    } else {
-        const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
-        const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
-        if (r < 0) return;                           // time de-interleaver still filling (k_finish flags it)
-        VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + (sc.start_bit >> 4), r, C.ti_slots - 1};
-        uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
-        viterbi_wave(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out, xs, ring);
-    }
+    if (!viterbi_item<false>(C, work[wi], nullptr, xs_all[wave], ring_all[wave]) && (threadIdx.x & 63) == 0)
+        C.requeue[1 + atomicAdd(C.requeue, 1u)] = (uint32_t)wi;              // [0] = count, then the items
+}
+
+// The codewords the first pass gave up on (normally none: the launch ends after reading the count).  VIT_RQ_BLOCKS workgroups
+// walk the list; every wave owns scratch_words_per_wave words of C.dec_scratch (the longest codeword's decision words).
+constexpr int VIT_RQ_BLOCKS = 64;
+__global__ __launch_bounds__(256) void k_viterbi_requeue(DevCtx C, const DevWork *__restrict__ work, uint32_t scratch_words_per_wave)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) int xs_all[4][84];
+    __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];
+    const uint32_t n = C.requeue[0];
+    const uint32_t me = blockIdx.x * 4 + wave;
+    uint32_t *dec = C.dec_scratch + (size_t)me * scratch_words_per_wave;
+    for (uint32_t i = me; i < n; i += VIT_RQ_BLOCKS * 4)
+        (void)viterbi_item<true>(C, work[C.requeue[1 + i]], dec, xs_all[wave], ring_all[wave]);
 }
 
 // stage-level: n_cw linear codewords of one profile (unit tests, BASELINE config 2 helper)
@@ -1052,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     __shared__ __attribute__((aligned(16))) int xs_all[4][84];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
-    viterbi_wave(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
+    (void)viterbi_wave<true>(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
 }
 
 // stage-level FFT: one workgroup per vector, natural order in and out
@@ -1087,6 +1118,10 @@ __global__ __launch_bounds__(256) void k_finish(DevCtx C, int n_frames)
     }
     for (int k = t; k < n_frames * 4; k += 256)
         C.msc_valid[(size_t)s * C.max_frames * 4 + k] = (!st.acq_fail && st.cif + k - 15 >= 0) ? 1 : 0;
+    if (s == 0 && t == 0) {                   // the list of k_viterbi / k_viterbi_requeue has been served
+        C.requeue[1 + C.requeue_cap] += C.requeue[0];      // running total (diagnostics: dabx_get_requeue_total)
+        C.requeue[0] = 0;
+    }
     __syncthreads();
     if (t == 0) {
         if (st.acq_fail) {                    // no null symbol found: skip ahead, stay unlocked

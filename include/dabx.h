@@ -248,6 +248,11 @@ typedef struct {
 } dabx_rawfile_info_t;
 DABX_API int dabx_rawfile_probe(const uint8_t *head, int n_bytes, dabx_rawfile_info_t *info);
 
+/* Diagnostics: codewords (all streams, all steps so far) whose survivor paths did not merge within 192 trellis steps, so that
+ * the Viterbi kernel had to decode them a second time with their decisions spilled to device memory (erased or tied input:
+ * silence, a sub-channel that is not there).  Zero on any live signal. */
+DABX_API int dabx_get_requeue_total(dabx_ctx *ctx, uint64_t *total);
+
 /* Timing of the last step, HIP events on the context's stream (ms):
  * [0] acquire+sync, [1] FFT/demap, [2] Viterbi, [3] super frames + CRC/state, [4] whole step */
 DABX_API int dabx_last_timing(dabx_ctx *ctx, float ms[5]);

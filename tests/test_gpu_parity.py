@@ -323,3 +323,37 @@ def test_lock_loss_and_reacquisition_matches_oracle(gpu_ctx_factory):
         assert (st["pos"], st["inc"], st["locked"], st["cif"], st["bad"], st["slope"]) == (so["pos"], so["inc"], so["locked"], so["cif"], so["bad"], so["slope"])
         locked.append(st["locked"])
     assert locked[0] == 1 and 0 in locked[1:] and locked[-1] == 1
+
+
+def test_silence_after_lock_takes_the_requeue_path_and_matches_the_oracle(gpu_ctx_factory):
+    """A recording that goes silent (u8 value 128 = zero: the flushed FIFO of the reference's input, inputdevice.cpp:80-85)
+    while the receiver is locked: the soft bits of those frames are all zero, every candidate of every trellis step ties, the
+    survivors never merge — the codewords are decoded a second time by k_viterbi_requeue with their decisions spilled to
+    device memory (the kernel's fallback; no scratch is held for codewords that merge).  Results equal the CPU checker's,
+    whose textbook Viterbi keeps the own path on a tie."""
+    sub = ob.subch_layout(4, 64) + [[192, 0, 3, 192]]                    # a long codeword too: 4614 steps
+    iq, fib, _ = ob.tx_generate(seed=77, n_frames=6, subch=sub, delay=5000, snr_db=22.0)
+    sig = np.concatenate([iq, np.full(2 * 8 * ob.TF, 128, dtype=np.uint8)])
+    ctx = gpu_ctx_factory(n_streams=2, fmt=0, ring_frames=16, max_frames=2)
+    orc = ob.Stream(subch=sub, ring_len=ctx.ring_samples)
+    for s in range(2):
+        ctx.set_subchannels(s, sub)
+        ctx.push(s, sig)
+    orc.push(sig)
+    total0 = ctx.requeue_total()
+    steps = 0
+    while ctx.frames_available() >= 2 and steps < 6:
+        ctx.process(2)
+        o = orc.process(2)
+        assert o["rc"] in (0, 2)
+        for s in range(2):
+            assert np.array_equal(ctx.sync(s), o["sync"]), steps
+            gf, gok = ctx.fib(s)
+            gm, gv = ctx.msc(s)
+            assert np.array_equal(gok, o["fib_ok"]) and np.array_equal(gv, o["msc_valid"]), steps
+            if o["rc"]:
+                assert np.array_equal(gf, o["fib"]), steps
+                assert np.array_equal(gm[gv.astype(bool)], o["msc"][o["msc_valid"].astype(bool)]), steps
+        steps += 1
+    assert steps >= 4
+    assert ctx.requeue_total() - total0 >= 8, "the silent frames' FIC codewords (all ties) must have gone through the requeue kernel"
