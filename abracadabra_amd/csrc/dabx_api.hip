@@ -608,6 +608,25 @@ int64_t dabx_push_resampled_from(dabx_ctx *c, int s, const void *src, int64_t n,
         // whenever it turns negative (inputdevicesrc.cpp:241-245).  The recursion is serial in float (every step rounds), so
         // the host runs it ahead into page-locked memory; the kernels do the arithmetic on the samples.
         const float R = static_cast<float>(2048e3 / static_cast<double>(static_cast<float>(in_rate_hz)));
+        if (R >= 0.5f) {
+            // up to 4096 kHz the recursion is exact integer arithmetic modulo 2^24 (dabx_resample.hip: k_farrow_fused): the schedule is
+            // closed form, the threads work it out themselves, nothing is computed or uploaded by the host
+            const uint32_t Ri = static_cast<uint32_t>(R * 16777216.0f), M0 = static_cast<uint32_t>(sh.rs_mu * 16777216.0f);
+            const uint64_t drop = static_cast<uint64_t>(n) * Ri;                  // how far mu travels over the block
+            const int64_t n_done = drop <= M0 ? 0 : static_cast<int64_t>((drop - M0 + 16777215u) >> 24);
+            n_out = n_done;
+            if (sh.wr + n_out - std::max<int64_t>(0, sh.st.pos - dabx::kTF) > len) return DABX_E_OVERRUN;
+            const rs::Sched sc = {M0, Ri};
+            const unsigned blocks = static_cast<unsigned>((n_done + 255) / 256);
+            if (src_fmt == DABX_FMT_S16) {
+                if (n_done) hipLaunchKernelGGL(rs::k_farrow_fused<1>, dim3(blocks), dim3(256), 0, q, in, sc, static_cast<int>(n_done), st, ring, len, sh.wr, R, gain, peak);
+                hipLaunchKernelGGL(rs::k_farrow_finish<1>, dim3(1), dim3(64), 0, q, in, sc, static_cast<int>(n_done), n, st);
+            } else {
+                if (n_done) hipLaunchKernelGGL(rs::k_farrow_fused<2>, dim3(blocks), dim3(256), 0, q, in, sc, static_cast<int>(n_done), st, ring, len, sh.wr, R, gain, peak);
+                hipLaunchKernelGGL(rs::k_farrow_finish<2>, dim3(1), dim3(64), 0, q, in, sc, static_cast<int>(n_done), n, st);
+            }
+            sh.rs_mu = static_cast<float>(static_cast<uint32_t>((static_cast<uint64_t>(M0) - drop) & 0xFFFFFFu)) * 5.9604644775390625e-08f;
+        } else {
         float *mu = nullptr;
         int32_t *seg = nullptr;
         int slot = 0;
@@ -644,6 +663,7 @@ int64_t dabx_push_resampled_from(dabx_ctx *c, int s, const void *src, int64_t n,
         if (n_done) hipLaunchKernelGGL(rs::k_farrow_outputs, dim3(blocks), dim3(256), 0, q, c->d_rs_A, n_done, st, ring, len, sh.wr, R, gain, peak);
         hipLaunchKernelGGL(rs::k_farrow_tail, dim3(1), dim3(64), 0, q, c->d_rs_A, n_done, st, c->d_rs_x);
         sh.rs_mu = m;
+        }
     }
     HIPCHK(hipGetLastError());
     if (async) c->copies_queued = true;                  // the next step waits for the copy stream

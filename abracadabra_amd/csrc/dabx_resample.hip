@@ -233,4 +233,133 @@ __global__ void k_farrow_open(const void *in, const int32_t *seg, const float *m
     for (int m = 0; m < FW_M; ++m) x_open[m] = x[m];
 }
 
+// ---- Transposed Farrow, one launch, for input rates up to 4096 kHz (R = 2048 kHz / rate >= 0.5).
+// There the reference's serial float recursion `mu -= R; if (mu < 0) { dump; mu += 1 }` (inputdevicesrc.cpp:241-245) is EXACT:
+// mu and R are multiples of 2^-24 below 1, so is every difference and every sum the recursion forms, and a float holds them
+// all.  With M = mu 2^24 and Ri = R 2^24 it is integer arithmetic modulo 2^24:
+//     mu after sample k      = ((M0 - (k + 1) Ri) mod 2^24) 2^-24
+//     dump number j (j >= 1) falls on sample floor((M0 + (j - 1) 2^24) / Ri)         (tests/test_resampler.py checks both)
+// so every thread finds its own segment and the schedule needs no host loop and no upload.  One thread per output: it
+// integrates its segment and evaluates the six polynomials (pass 1 of the two-kernel form) into LDS, then adds the six
+// contributions of its output in the reference's order (pass 2).  The five segments before the block are recomputed by the
+// block (or come from the carried state).
+struct Sched { uint32_t M0, Ri; };
+__device__ __forceinline__ int64_t farrow_seg(const Sched &sc, int64_t j)          // first sample of segment j
+{
+    if (j <= 0) return 0;
+    const uint64_t num = (uint64_t)sc.M0 + ((uint64_t)(j - 1) << 24);
+    int64_t k = (int64_t)((double)num / (double)sc.Ri);                            // off by one at most: corrected exactly
+    while ((uint64_t)(k + 1) * sc.Ri <= num) ++k;
+    while ((uint64_t)k * sc.Ri > num) --k;
+    return k;
+}
+__device__ __forceinline__ float farrow_mu(const Sched &sc, int64_t k)             // mu sample k is integrated with
+{
+    const uint64_t v = (uint64_t)sc.M0 - (uint64_t)(k + 1) * sc.Ri;
+    return (float)(uint32_t)(v & 0xFFFFFFu) * 5.9604644775390625e-08f;             // 2^-24: exact
+}
+
+// integrators of segment j over samples [k0, k1), continued from the carried state when j = 0; then A_n = sum_m x[m] coef[n][m]
+template <int FMT>
+__device__ __forceinline__ void farrow_segment(const void *in, const Sched &sc, int64_t j, int64_t k0, int64_t k1, const State *st, float2 x[FW_M])
+{
+#pragma unroll
+    for (int m = 0; m < FW_M; ++m) x[m] = j == 0 ? st->fw_x[m] : make_float2(0.0f, 0.0f);
+    for (int64_t k = k0; k < k1; ++k) {
+        float2 v = in_sample<FMT>(in, k);
+        const float u = farrow_mu(sc, k);
+        x[0].x = x[0].x + v.x; x[0].y = x[0].y + v.y;
+#pragma unroll
+        for (int m = 1; m < FW_M; ++m) {
+            v.x = v.x * u; v.y = v.y * u;
+            x[m].x = x[m].x + v.x; x[m].y = x[m].y + v.y;
+        }
+    }
+}
+__device__ __forceinline__ void farrow_poly(const float2 x[FW_M], float2 A[FW_N])
+{
+#pragma unroll
+    for (int n = 0; n < FW_N; ++n) {
+        float aI = 0.0f, aQ = 0.0f;
+#pragma unroll
+        for (int m = 0; m < FW_M; ++m) {
+            float p = x[m].x * fw_coef[n][m];
+            aI = aI + p;
+            p = x[m].y * fw_coef[n][m];
+            aQ = aQ + p;
+        }
+        A[n] = make_float2(aI, aQ);
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_farrow_fused(const void *in, Sched sc, int n_done, const State *st, short2 *ring, int64_t ring_len, int64_t wr,
+                                                      float R, float gain, uint32_t *peak)
+{
+    __shared__ float2 A[256 + FW_N - 1][FW_N];
+    const int t = threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.x * 256;
+    for (int row = t; row < 256 + FW_N - 1; row += 256) {
+        const int64_t j = j0 - (FW_N - 1) + row;
+        float2 a[FW_N];
+        if (j < 0) {
+#pragma unroll
+            for (int n = 0; n < FW_N; ++n) a[n] = st->fw_a[FW_N - 1 + j][n];
+        } else if (j < n_done) {
+            float2 x[FW_M];
+            farrow_segment<FMT>(in, sc, j, farrow_seg(sc, j), farrow_seg(sc, j + 1), st, x);
+            farrow_poly(x, a);
+        } else {
+#pragma unroll
+            for (int n = 0; n < FW_N; ++n) a[n] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int n = 0; n < FW_N; ++n) A[row][n] = a[n];
+    }
+    __syncthreads();
+    const int64_t j = j0 + t;
+    short2 o16 = make_short2(0, 0);
+    if (j < n_done) {
+        float yI = 0.0f, yQ = 0.0f;
+#pragma unroll
+        for (int i = FW_N - 1; i >= 0; --i) {                     // y = ((((A5(j-5) + A4(j-4)) + A3(j-3)) + A2(j-2)) + A1(j-1)) + A0(j)
+            const float2 a = A[t + (FW_N - 1) - i][i];
+            yI = yI + a.x; yQ = yQ + a.y;
+        }
+        o16 = to_s16(make_float2(R * yI, R * yQ), gain);
+        ring_store(ring, ring_len, wr + j, o16);
+    }
+    note_peak(peak, o16, j < n_done);
+}
+
+// carry-over of the fused form: the polynomial outputs of the last five finished segments and the integrators of the open one,
+// recomputed from the input (one small workgroup, after k_farrow_fused)
+template <int FMT>
+__global__ void k_farrow_finish(const void *in, Sched sc, int n_done, int64_t n_in, State *st)
+{
+    const int t = threadIdx.x;                            // 64 threads
+    float2 a[FW_N], xo[FW_M];
+    if (t < FW_N - 1) {                                   // row t of the new fw_a: segment n_done - 5 + t
+        const int64_t j = (int64_t)n_done - (FW_N - 1) + t;
+        if (j < 0) {
+#pragma unroll
+            for (int n = 0; n < FW_N; ++n) a[n] = st->fw_a[FW_N - 1 + j][n];
+        } else {
+            float2 x[FW_M];
+            farrow_segment<FMT>(in, sc, j, farrow_seg(sc, j), farrow_seg(sc, j + 1), st, x);
+            farrow_poly(x, a);
+        }
+    }
+    if (t == FW_N - 1) farrow_segment<FMT>(in, sc, n_done, farrow_seg(sc, n_done), n_in, st, xo);
+    __syncthreads();
+    if (t < FW_N - 1) {
+#pragma unroll
+        for (int n = 0; n < FW_N; ++n) st->fw_a[t][n] = a[n];
+    }
+    if (t == FW_N - 1) {
+#pragma unroll
+        for (int m = 0; m < FW_M; ++m) st->fw_x[m] = xo[m];
+    }
+}
+
 }  // namespace rs

@@ -202,6 +202,21 @@ class Context:
             _chk(int(n))
         return int(n)
 
+    def push_resampled_from(self, stream, iq, in_rate_hz, gain=1.0, kind=2):
+        """as push_resampled with the source kinds of push(): kind 2 = iq lives in memory from alloc_pinned(), the copy and the
+        converter kernels are queued (flush_copies() or the next waited step completes them)"""
+        fmt = {np.dtype(np.int16): 1, np.dtype(np.float32): 2}[iq.dtype]
+        self.L.dabx_push_resampled_from.restype = C.c_int64
+        self.L.dabx_push_resampled_from.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_float, C.c_int]
+        n = self.L.dabx_push_resampled_from(self.h, stream, iq.ctypes.data, iq.size // 2, fmt, float(in_rate_hz), float(gain), int(kind))
+        if n < 0:
+            _chk(int(n))
+        return int(n)
+
+    def flush_copies(self):
+        self.L.dabx_flush_copies.argtypes = [C.c_void_p]
+        _chk(self.L.dabx_flush_copies(self.h))
+
     def read_ring(self, stream, start, n):
         out = np.zeros(2 * n, dtype=np.int16 if self.fmt else np.uint8)
         self.L.dabx_read_ring.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]

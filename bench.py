@@ -329,6 +329,39 @@ def pin_to_gpu_numa_node(torch, dev):
         return None
 
 
+def resampler_leg(dev):
+    """Throughput of the sample-rate converters in front of the ring (dabx_push_resampled_from, page-locked source, asynchronous):
+    s16 IQ at 4.096 Msps through the 43-tap half-band decimator, at 2.4 Msps through the transposed Farrow structure (closed-form
+    schedule) and at 6 Msps (schedule run by the host: R < 0.5).  One stream; each push is one DAB frame of output (196 608 samples)."""
+    import abracadabra_amd as aa
+    ctx = aa.Context(n_streams=1, fmt=1, ring_frames=8, max_frames=1, device=dev)
+    out = {"unit": "complex Msps", "chunk": "one transmission frame of output per push (96 ms of signal)"}
+    try:
+        for name, rate in (("half_band_4096k", 4096e3), ("farrow_2400k", 2400e3), ("farrow_6000k_host_schedule", 6000e3)):
+            n_in = int(TF * rate / 2048e3)
+            n_in -= n_in & 1
+            pinned = ctx.alloc_pinned(4 * n_in)
+            pinned.view(np.int16)[:] = np.random.default_rng(1).integers(-8000, 8000, 2 * n_in).astype(np.int16)
+            src = pinned.view(np.int16)
+            for _ in range(3):
+                ctx.set_write_pos(0, 0)
+                ctx.push_resampled_from(0, src, rate, 1.0, kind=2)
+            ctx.flush_copies()
+            reps, produced = 200, 0
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.set_write_pos(0, 0)                                 # (the same ring segment every time: nothing decodes here)
+                produced += ctx.push_resampled_from(0, src, rate, 1.0, kind=2)
+            ctx.flush_copies()
+            dt = time.perf_counter() - t0
+            out[name] = {"in_msps": round(reps * n_in / dt / 1e6, 1), "out_msps": round(produced / dt / 1e6, 1),
+                         "x_realtime": round(produced / 2.048e6 / dt, 1), "us_per_push": round(dt / reps * 1e6, 1)}
+            ctx.free_pinned(pinned)
+    finally:
+        ctx.close()
+    return out
+
+
 def legacy_leg(args):
     """ONE ensemble through the reference's 24-function API (libdabsdr.so.4 drop-in), un-paced C host (tools/legacy_rate.c):
     the shape of BASELINE configs[0] / [2].  Both legs must decode without a FIB error; the service leg without an AU CRC error."""
@@ -438,10 +471,11 @@ def run_rank(args, engine_factory=None):
             dist.barrier()                       # all ranks pull from the host at the same time: that is the point
         pcie = pcie_leg(args, dev, streams, sub)
 
-    legacy = None
+    legacy = resamp = None
     if gpu and world == 1 and not args.no_legacy:
         engine.close()
         legacy = legacy_leg(args)
+        resamp = resampler_leg(dev)
 
     my_elapsed = elapsed
     pcie_v = pcie["pinned_overlapped"]["value"] if pcie else 0.0
@@ -508,6 +542,8 @@ def run_rank(args, engine_factory=None):
             out["pcie_inclusive"] = pcie
             if world > 1:
                 out["pcie_inclusive"]["all_ranks_pinned_overlapped_sum"] = round(pcie_sum, 1)
+        if resamp is not None:
+            out["resampler_prestage"] = resamp
         if legacy is not None:
             out["legacy_single_stream"] = legacy
             if not legacy.get("ok"):

@@ -74,6 +74,35 @@ def test_level_detector_follows_the_reference_recursion():
     assert 0.85 * 1e4 < r.level() < 0.95 * 1e4                                          # 4.9 ms of silence: exp(-4.9/50) = 0.906
 
 
+@pytest.mark.parametrize("rate", [2400000.0, 2500000.0, 3072000.0, 4000000.0, 2048001.0, 4095999.0, 2304000.0])
+def test_farrow_schedule_is_exact_integer_arithmetic_up_to_4096_khz(rate):
+    """The reference's schedule `mu -= R; if (mu < 0) { dump; mu += 1 }` (inputdevicesrc.cpp:241-245) in binary32, against the
+    closed form the GPU threads use for R >= 0.5 (dabx_resample.hip: farrow_mu / farrow_seg): mu and R are multiples of 2^-24
+    below 1, every difference and sum the recursion forms is one too and fits a float, so it is arithmetic modulo 2^24."""
+    R = np.float32(2048e3 / float(np.float32(rate)))
+    assert 0.5 <= R < 1.0
+    Ri = int(float(R) * 2 ** 24)
+    assert Ri == float(R) * 2 ** 24
+    n = 40000
+    for m0 in (0.0, 0.25, 0.7312345):
+        M0 = int(round(m0 * 2 ** 24))
+        m = np.float32(M0 / 2 ** 24)
+        mu, seg = np.empty(n, np.float32), [0]
+        for k in range(n):                                         # the reference's recursion
+            m = np.float32(m - R)
+            if m < 0:
+                m = np.float32(m + np.float32(1.0))
+                seg.append(k)
+            mu[k] = m
+        k = np.arange(1, n + 1, dtype=np.int64)
+        U = M0 - k * Ri
+        assert np.array_equal(mu, (np.mod(U, 2 ** 24).astype(np.float64) / 2 ** 24).astype(np.float32))
+        n_done = 0 if n * Ri <= M0 else (n * Ri - M0 + 2 ** 24 - 1) >> 24
+        assert n_done == len(seg) - 1
+        j = np.arange(1, n_done + 1, dtype=np.int64)
+        assert seg[1:] == [int(v) for v in (M0 + (j - 1) * 2 ** 24) // Ri]
+
+
 # ------------------------------------------------------------------------------------------------------------- GPU
 def _chunks(n, sizes):
     out, a = [], 0
@@ -85,7 +114,8 @@ def _chunks(n, sizes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rate,dtype", [(4096e3, np.int16), (4096e3, np.float32), (2400e3, np.int16), (3000e3, np.float32), (2048e3, np.float32)])
+@pytest.mark.parametrize("rate,dtype", [(4096e3, np.int16), (4096e3, np.float32), (2400e3, np.int16), (3000e3, np.float32), (2048e3, np.float32),
+                                        (6000e3, np.int16), (10e6, np.float32), (2048001.0, np.int16), (4095999.0, np.float32)])
 def test_gpu_resampler_equals_the_restatement(gpu_ctx_factory, rate, dtype):
     rng = np.random.default_rng(7)
     n = 150000
@@ -162,3 +192,27 @@ def test_gpu_resampled_stream_through_a_small_ring(gpu_ctx_factory):
             assert gok.all() and np.array_equal(gf[0], fib[done])
             done += 1
     assert done >= nf - 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate", [4096e3, 2400e3, 6000e3])
+def test_gpu_resampler_asynchronous_pushes_from_pinned_memory(gpu_ctx_factory, rate):
+    """dabx_push_resampled_from(DABX_SRC_PINNED): staging copies and converter kernels queued on the copy stream, no
+    synchronisation per push; the ring holds what the restatement computes, bit for bit"""
+    rng = np.random.default_rng(11)
+    n = 400000
+    x = rng.integers(-15000, 15000, 2 * n).astype(np.int16)
+    ctx = gpu_ctx_factory(n_streams=1, fmt=1, ring_frames=4, max_frames=1)
+    pinned = ctx.alloc_pinned(x.nbytes)
+    buf = pinned.view(np.int16)
+    buf[:] = x
+    orc = ob.Resampler(rate)
+    total, want = 0, []
+    step = 2 * 65536
+    for a in range(0, 2 * n, step):
+        total += ctx.push_resampled_from(0, buf[a:a + step], rate, 1.0, kind=2)
+        want.append(ob.to_s16(orc.process(x[a:a + step].astype(np.float32))))
+    ctx.flush_copies()
+    got = ctx.read_ring(0, 0, total)
+    assert np.array_equal(got, np.concatenate(want)) and total > 100000
+    ctx.free_pinned(pinned)
