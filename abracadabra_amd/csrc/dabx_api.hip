@@ -82,6 +82,8 @@ struct dabx_ctx {
     uint32_t *d_info = nullptr;
     uint32_t *d_prbs = nullptr, *d_scratch = nullptr, *d_requeue = nullptr;
     uint32_t rq_words_per_wave = 0;
+    uint64_t *d_clock = nullptr;            // clock probe of k_viterbi (with timing enabled): [n_work / 4096 + 1][2]
+    size_t clock_cap = 0;
     size_t work_cap_rq = 0;                 // entries the requeue list holds (its running total sits behind them)
     DevWork *d_work = nullptr;
     float2 *d_W = nullptr, *d_nhi = nullptr, *d_nlo = nullptr;
@@ -136,7 +138,7 @@ struct dabx_ctx {
         c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car, d_cordic};
         c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
         c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
-        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.requeue = d_requeue; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
+        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.requeue = d_requeue; c.clock_probe = timing ? d_clock : nullptr; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
         c.ring_len = cfg.ring_samples; c.ring_bytes = stride();
         c.n_streams = cfg.n_streams; c.max_frames = cfg.max_frames; c.ti_slots = ti_slots;
         c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0; c.requeue_cap = static_cast<int32_t>(work_cap_rq);
@@ -227,6 +229,13 @@ int build_work(dabx_ctx *c, int n_frames)
         c->work_cap = all.size();
     }
     c->rq_words_per_wave = static_cast<uint32_t>(words_per_wave);
+    if (all.size() / 4096 + 1 > c->clock_cap) {
+        if (c->d_clock) (void)hipFree(c->d_clock);
+        c->d_clock = nullptr; c->clock_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_clock), (all.size() / 4096 + 1) * 2 * sizeof(uint64_t)));
+        c->clock_cap = all.size() / 4096 + 1;
+        HIPCHK(hipMemset(c->d_clock, 0, c->clock_cap * 2 * sizeof(uint64_t)));
+    }
     if (!all.empty()) HIPCHK(hipMemcpy(c->d_work, all.data(), all.size() * sizeof(DevWork), hipMemcpyHostToDevice));
     if (blocks * 64 > c->scratch_words) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -407,7 +416,7 @@ void dabx_destroy(dabx_ctx *c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
-                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_requeue, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_requeue, c->d_clock, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic, c->d_rs_state, c->d_rs_in, c->d_rs_mu, c->d_rs_seg, c->d_rs_A, c->d_rs_x};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -1136,6 +1145,21 @@ int dabx_enable_timing(dabx_ctx *c, int on)
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->pending) return DABX_E_ARG;
     c->timing = on != 0;
+    return DABX_OK;
+}
+
+int dabx_last_shader_clock(dabx_ctx *c, double *ghz)
+{
+    if (!c || !ghz) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    if (c->pending || !c->timing || !c->d_clock) return DABX_E_ARG;
+    const size_t n = static_cast<size_t>(c->n_work) / 4096 + 1;
+    std::vector<uint64_t> h(2 * n);
+    HIPCHK(hipMemcpy(h.data(), c->d_clock, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    double cyc = 0, ticks = 0;
+    for (size_t i = 0; i < n; ++i) { cyc += static_cast<double>(h[2 * i]); ticks += static_cast<double>(h[2 * i + 1]); }
+    *ghz = ticks > 0 ? cyc / ticks * 0.1 : 0.0;      // s_memrealtime counts at 100 MHz
     return DABX_OK;
 }
 

@@ -1054,8 +1054,18 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     if (wi >= n_work) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][84];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
+    // shader clock under load: one wave in 4096 brackets its codeword with the shader-cycle counter (s_memtime) and the
+    // constant 100 MHz counter (s_memrealtime); the host reads the ratio (bench.py: valu_issue_frac at the measured clock)
+    const bool probe = C.clock_probe && (wi & 4095) == 0;
+    uint64_t c0 = 0, r0 = 0;
+    if (probe) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (!viterbi_item<false>(C, work[wi], nullptr, xs_all[wave], ring_all[wave]) && (threadIdx.x & 63) == 0)
         C.requeue[1 + atomicAdd(C.requeue, 1u)] = (uint32_t)wi;              // [0] = count, then the items
+    if (probe && (threadIdx.x & 63) == 0) {
+        const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        C.clock_probe[2 * (wi >> 12)] = c1 - c0;
+        C.clock_probe[2 * (wi >> 12) + 1] = r1 - r0;
+    }
 }
 
 // The codewords the first pass gave up on (normally none: the launch ends after reading the count).  VIT_RQ_BLOCKS workgroups

@@ -23,7 +23,7 @@ DABX_SYMBOLS = [
     "dabx_push_resampled", "dabx_push_resampled_from", "dabx_get_input_peak", "dabx_get_superframe_pos", "dabx_read_ring", "dabx_flush_copies",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
-    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum", "dabx_get_null_spectra", "dabx_get_requeue_total",
+    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum", "dabx_get_null_spectra", "dabx_get_requeue_total", "dabx_last_shader_clock",
 ]
 
 
@@ -284,6 +284,13 @@ class Context:
         ok, bad = C.c_int64(), C.c_int64()
         _chk(self.L.dabx_get_fib_counts(self.h, C.byref(ok), C.byref(bad)))
         return ok.value, bad.value
+
+    def last_shader_clock(self):
+        """GHz the Viterbi kernel of the last step ran at (timing must be enabled)"""
+        g = C.c_double()
+        self.L.dabx_last_shader_clock.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.dabx_last_shader_clock(self.h, C.byref(g)))
+        return g.value
 
     def requeue_total(self):
         """codewords decoded a second time with spilled decisions (survivors did not merge), all steps so far"""

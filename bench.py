@@ -145,6 +145,9 @@ class GpuEngine:
     def fib_counts(self):
         return self.ctx.fib_counts()
 
+    def shader_clock_ghz(self):
+        return self.ctx.last_shader_clock()
+
     def fib(self, s):
         return self.ctx.fib(s)
 
@@ -444,6 +447,7 @@ def run_rank(args, engine_factory=None):
     barrier()
     elapsed = time.perf_counter() - t0
     ok, bad = engine.fib_counts()
+    clock_ghz = engine.shader_clock_ghz() if hasattr(engine, "shader_clock_ghz") else None
 
     # ---- correctness of what was just timed (outside the timed region)
     checked, mism = verify(engine, streams, S, F, P)
@@ -495,8 +499,8 @@ def run_rank(args, engine_factory=None):
         traffic, insts_valu, prof_src = profile_counters(S, F) if args.nsub == 18 else (None, None, None)
         d_traffic, d_insts, _ = profile_counters(S, F, "k_demod") if args.nsub == 18 else (None, None, None)
 
-        def issue_frac(insts, ms):                # wave-instructions x 2 cycles over the SIMD-cycles of the launch
-            return round(insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 4) if insts and ms > 0 else None
+        def issue_frac(insts, ms, hz=CLOCK_HZ):   # wave-instructions x 2 cycles over the SIMD-cycles of the launch
+            return round(insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * ms * 1e-3 * hz), 4) if insts and ms > 0 and hz else None
 
         out = {
             "metric": "DAB Mode-I ensembles decoded x real-time, all GPUs together (2048-FFT + de-interleave + Viterbi, full FIC+MSC); per GPU: x_realtime_per_gpu",
@@ -517,9 +521,16 @@ def run_rank(args, engine_factory=None):
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": prof_src, "algorithmic_bytes_per_launch": S * F * BYTES_VITERBI,
                          "valu_issue_frac": issue_frac(insts_valu, vit_ms), "insts_valu_per_launch": insts_valu,
+                         "shader_clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
+                         "valu_issue_frac_at_measured_clock": issue_frac(insts_valu, vit_ms, (clock_ghz or 0) * 1e9),
                          "note": "the kernel is bound by VALU issue (DESIGN.md §7), not by HBM: `frac` is the HBM fraction the contract asks for and is "
-                                 "small by construction (SURVEY.md §0.8); `valu_issue_frac` = SQ_INSTS_VALU (committed PMC pass of this command) x 2 cycles "
-                                 "/ (1024 SIMDs x launch time measured here x 2.4 GHz) is the fraction of the binding resource",
+                                 "small by construction (SURVEY.md §0.8); `valu_issue_frac` = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x launch time x 2.4 GHz "
+                                 "nominal) is the fraction of the binding resource, `..._at_measured_clock` the same with the shader clock the kernel "
+                                 "measured on itself in THIS run (s_memtime against the 100 MHz counter: the chip lowers its clock under this load).  "
+                                 "Two runs meet in these figures: `traffic` and `insts_valu_per_launch` come from the committed PMC passes of this same "
+                                 "command (`traffic_source`; a PMC pass cannot share a run with the timing), launch time and clock from this run.  "
+                                 "Both formulas price every instruction at the full rate (2 cycles): v_max_i32, DPP forms and the MFMA issue cost 4, "
+                                 "so the vector ALU is busier than the fraction says (DESIGN.md §5)",
                          "acs_per_s": round(acs_rate, 0),
                          "chain_algorithmic_GBps": round(value / world / FRAME_S * BYTES_CHAIN / 1e9, 2)},
             "other_kernels": {"k_demod": {"bound": "hbm", "algorithmic_bytes_per_launch": S * F * BYTES_DEMOD,

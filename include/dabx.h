@@ -256,6 +256,9 @@ DABX_API int dabx_get_requeue_total(dabx_ctx *ctx, uint64_t *total);
 /* Timing of the last step, HIP events on the context's stream (ms):
  * [0] acquire+sync, [1] FFT/demap, [2] Viterbi, [3] super frames + CRC/state, [4] whole step */
 DABX_API int dabx_last_timing(dabx_ctx *ctx, float ms[5]);
+/* With timing enabled: the shader clock (GHz) the Viterbi kernel of the last step ran at, measured inside the kernel (shader-cycle
+ * counter against the constant 100 MHz counter, over sampled codewords).  The GPU lowers its clock under this load. */
+DABX_API int dabx_last_shader_clock(dabx_ctx *ctx, double *ghz);
 DABX_API int dabx_enable_timing(dabx_ctx *ctx, int on);
 
 #ifdef __cplusplus
