@@ -82,8 +82,9 @@ struct dabx_ctx {
     uint32_t *d_info = nullptr;
     uint32_t *d_prbs = nullptr, *d_scratch = nullptr, *d_requeue = nullptr;
     uint32_t rq_words_per_wave = 0;
-    uint64_t *d_clock = nullptr;            // clock probe of k_viterbi (with timing enabled): [n_work / 4096 + 1][2]
-    size_t clock_cap = 0;
+    uint64_t *d_clock = nullptr;            // k_clock_monitor (timing enabled): {shader cycles, 100 MHz ticks} beside the last k_viterbi, then the stop flag
+    hipStream_t mon_stream = nullptr;
+    hipEvent_t mon_start = nullptr;
     size_t work_cap_rq = 0;                 // entries the requeue list holds (its running total sits behind them)
     DevWork *d_work = nullptr;
     float2 *d_W = nullptr, *d_nhi = nullptr, *d_nlo = nullptr;
@@ -138,7 +139,7 @@ struct dabx_ctx {
         c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car, d_cordic};
         c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
         c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
-        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.requeue = d_requeue; c.clock_probe = timing ? d_clock : nullptr; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
+        c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.requeue = d_requeue; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
         c.ring_len = cfg.ring_samples; c.ring_bytes = stride();
         c.n_streams = cfg.n_streams; c.max_frames = cfg.max_frames; c.ti_slots = ti_slots;
         c.msc_stride = DABX_MSC_STRIDE; c.fic_info_off = 0; c.requeue_cap = static_cast<int32_t>(work_cap_rq);
@@ -229,13 +230,7 @@ int build_work(dabx_ctx *c, int n_frames)
         c->work_cap = all.size();
     }
     c->rq_words_per_wave = static_cast<uint32_t>(words_per_wave);
-    if (all.size() / 4096 + 1 > c->clock_cap) {
-        if (c->d_clock) (void)hipFree(c->d_clock);
-        c->d_clock = nullptr; c->clock_cap = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_clock), (all.size() / 4096 + 1) * 2 * sizeof(uint64_t)));
-        c->clock_cap = all.size() / 4096 + 1;
-        HIPCHK(hipMemset(c->d_clock, 0, c->clock_cap * 2 * sizeof(uint64_t)));
-    }
+
     if (!all.empty()) HIPCHK(hipMemcpy(c->d_work, all.data(), all.size() * sizeof(DevWork), hipMemcpyHostToDevice));
     if (blocks * 64 > c->scratch_words) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -415,8 +410,11 @@ void dabx_destroy(dabx_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->mon_stream) { (void)hipStreamSynchronize(c->mon_stream); (void)hipStreamDestroy(c->mon_stream); }
+    if (c->mon_start) (void)hipEventDestroy(c->mon_start);
+    if (c->d_clock) (void)hipFree(c->d_clock);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
-                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_requeue, c->d_clock, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
+                    c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_requeue, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
                     c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic, c->d_rs_state, c->d_rs_in, c->d_rs_mu, c->d_rs_seg, c->d_rs_A, c->d_rs_x};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -814,7 +812,20 @@ int dabx_process_async(dabx_ctx *c, int n_frames)
     }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[2], q));
     if (c->n_work) {
+        if (c->timing) {                    // the clock monitor runs beside k_viterbi on a stream of its own, until the flag set behind it
+            if (!c->d_clock) {
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_clock), 3 * sizeof(uint64_t)));
+                HIPCHK(hipStreamCreateWithFlags(&c->mon_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&c->mon_start, hipEventDisableTiming));
+            }
+            HIPCHK(hipMemsetAsync(c->d_clock, 0, 3 * sizeof(uint64_t), q));
+            HIPCHK(hipEventRecord(c->mon_start, q));
+            HIPCHK(hipStreamWaitEvent(c->mon_stream, c->mon_start, 0));
+            hipLaunchKernelGGL(k_clock_monitor, dim3(1), dim3(64), 0, c->mon_stream, c->d_clock, reinterpret_cast<const uint32_t *>(c->d_clock + 2),
+                               static_cast<uint64_t>(5000000));      // at most 50 ms
+        }
         hipLaunchKernelGGL(k_viterbi, dim3((c->n_work + 3) / 4), dim3(256), 0, q, d, c->d_work, c->n_work);
+        if (c->timing) HIPCHK(hipMemsetAsync(c->d_clock + 2, 1, sizeof(uint32_t), q));
         hipLaunchKernelGGL(k_viterbi_requeue, dim3(VIT_RQ_BLOCKS), dim3(256), 0, q, d, c->d_work, c->rq_words_per_wave);
     }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[5], q));
@@ -1154,12 +1165,11 @@ int dabx_last_shader_clock(dabx_ctx *c, double *ghz)
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->cfg.device);
     if (c->pending || !c->timing || !c->d_clock) return DABX_E_ARG;
-    const size_t n = static_cast<size_t>(c->n_work) / 4096 + 1;
-    std::vector<uint64_t> h(2 * n);
-    HIPCHK(hipMemcpy(h.data(), c->d_clock, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    double cyc = 0, ticks = 0;
-    for (size_t i = 0; i < n; ++i) { cyc += static_cast<double>(h[2 * i]); ticks += static_cast<double>(h[2 * i + 1]); }
-    *ghz = ticks > 0 ? cyc / ticks * 0.1 : 0.0;      // s_memrealtime counts at 100 MHz
+    HIPCHK(hipStreamSynchronize(c->mon_stream));
+    uint64_t h[2] = {0, 0};
+    HIPCHK(hipMemcpy(h, c->d_clock, sizeof h, hipMemcpyDeviceToHost));
+    // s_memrealtime counts at 100 MHz; a monitor that was scheduled only after the flag had been set measured nothing
+    *ghz = h[1] > 1000 ? static_cast<double>(h[0]) / static_cast<double>(h[1]) * 0.1 : 0.0;
     return DABX_OK;
 }
 

@@ -105,7 +105,6 @@ struct DevCtx {
     uint32_t *dec_scratch;      // k_viterbi_requeue: per wave the decision words of one codeword, 64 words per 24 trellis steps
     uint32_t *requeue;          // [0] number of codewords k_viterbi gave up on (survivors did not merge), [1..cap] their work
                                 // indices, [1 + cap] running total over the steps
-    uint64_t *clock_probe;      // optional (dabx_enable_timing): per 4096th codeword of k_viterbi {shader cycles, 100 MHz ticks}
     float *spectrum;            // [S][2048] |FFT|^2 of the last frame's PRS window, natural bin order; may be null
     float *null_spectrum;       // [S][F][2048] same for 2048 samples in the middle of every frame's null symbol (noise level, TII); may be null
     int64_t ring_len;           // samples

@@ -1054,18 +1054,27 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     if (wi >= n_work) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][84];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
-    // shader clock under load: one wave in 4096 brackets its codeword with the shader-cycle counter (s_memtime) and the
-    // constant 100 MHz counter (s_memrealtime); the host reads the ratio (bench.py: valu_issue_frac at the measured clock)
-    const bool probe = C.clock_probe && (wi & 4095) == 0;
-    uint64_t c0 = 0, r0 = 0;
-    if (probe) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (!viterbi_item<false>(C, work[wi], nullptr, xs_all[wave], ring_all[wave]) && (threadIdx.x & 63) == 0)
         C.requeue[1 + atomicAdd(C.requeue, 1u)] = (uint32_t)wi;              // [0] = count, then the items
-    if (probe && (threadIdx.x & 63) == 0) {
-        const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
-        C.clock_probe[2 * (wi >> 12)] = c1 - c0;
-        C.clock_probe[2 * (wi >> 12) + 1] = r1 - r0;
+}
+
+// Shader clock under load (timing mode only): ONE wave, launched on a stream of its own beside k_viterbi, brackets the time until
+// the host-queued stop flag appears with the shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime);
+// the ratio is the clock the chip held meanwhile (bench.py: valu_issue_frac at the measured clock).  Not inside k_viterbi: that
+// kernel sits at exactly 64 vector registers (8 waves per SIMD), and every way of putting the two time stamps into it cost a 65th
+// (measured: 1.59 -> 1.68 ms).  `max_ticks` bounds the wait whatever happens to the flag.
+__global__ void k_clock_monitor(uint64_t *out, const uint32_t *stop, uint64_t max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t c1 = c0, r1 = r0;
+    for (;;) {
+        __builtin_amdgcn_s_sleep(32);
+        c1 = __builtin_readcyclecounter(); r1 = __builtin_amdgcn_s_memrealtime();
+        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || r1 - r0 > max_ticks) break;
     }
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
 }
 
 // The codewords the first pass gave up on (normally none: the launch ends after reading the count).  VIT_RQ_BLOCKS workgroups
