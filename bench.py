@@ -442,8 +442,11 @@ def run_rank(args, engine_factory=None):
     barrier()
     t0 = time.perf_counter()
     phase_ms = np.zeros(5)
+    per_step = []
     for _ in range(args.steps):
-        phase_ms += np.array(engine.step())
+        ms = np.array(engine.step())
+        phase_ms += ms
+        per_step.append(float(ms[4]))
     barrier()
     elapsed = time.perf_counter() - t0
     ok, bad = engine.fib_counts()
@@ -516,7 +519,9 @@ def run_rank(args, engine_factory=None):
             "fib_crc_ok": ok, "fib_crc_bad": bad, "payload_checked": checked, "payload_mismatch": mism,
             "kernel_ms_per_step": {"sync": round(phase_ms[0] / args.steps, 3), "fft_demap": round(dem_ms, 3),
                                    "viterbi": round(vit_ms, 3), "crc_state": round(phase_ms[3] / args.steps, 3),
-                                   "all": round(phase_ms[4] / args.steps, 3)},
+                                   "all": round(phase_ms[4] / args.steps, 3),
+                                   "all_min_median_max_over_steps": [round(float(np.min(per_step)), 3), round(float(np.median(per_step)), 3),
+                                                                     round(float(np.max(per_step)), 3)]},
             "roofline": {"kernel": "k_viterbi", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": prof_src, "algorithmic_bytes_per_launch": S * F * BYTES_VITERBI,

@@ -43,7 +43,7 @@ def main(tag, streams=256, frames=8, timed=40):
             out["pmc"].setdefault(k, {}).update(
                 {c: {"mean": sum(v) / len(v), "max": max(v), "dispatches": len(v)} for c, v in d.items()})
     json.dump(out, open(os.path.join(dst, f"{tag}_rocprofv3.json"), "w"), indent=1)
-    traffic = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline",
+    traffic = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_... (separate passes, tools/profile.sh) -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-pcie --no-legacy",
                "workload": {"streams": streams, "frames_per_step": frames}, "kernels": {}}
     for k, d in out["pmc"].items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d and ("k_" in k):
@@ -52,7 +52,11 @@ def main(tag, streams=256, frames=8, timed=40):
                                      "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
             for c, key in (("SQ_INSTS_VALU", "insts_valu_per_launch"), ("SQ_INSTS_SALU", "insts_salu_per_launch"),
                            ("SQ_INSTS_LDS", "insts_lds_per_launch"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"),
-                           ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles")):
+                           ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles"),
+                           # in units of four cycles, summed over the waves (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES)
+                           ("SQ_WAVE_CYCLES", "wave_quadcycles"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu_quadcycles"),
+                           ("SQ_ACTIVE_INST_LDS", "active_inst_lds_quadcycles"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_quadcycles"),
+                           ("SQ_WAIT_ANY", "wait_any_quadcycles"), ("SQ_WAIT_INST_ANY", "wait_inst_any_quadcycles"), ("SQ_WAVES", "waves")):
                 if c in d:
                     traffic["kernels"][k][key] = int(d[c]["max"])
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
