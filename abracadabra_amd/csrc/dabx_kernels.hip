@@ -37,55 +37,66 @@ constexpr int SLOPE_MAX = 60 << 16;        // sampling-clock tracker: |drift| <=
 constexpr int SCO_MIN = 1 << 16;           // de-rotate the differential product from this drift on: 1 sample per frame = 5.1 ppm
 constexpr int TI_SEG = CIFBITS / 16;   // bytes per residue class in a residue-major MSC row
 
-struct cf { float r, i; };
+// A complex value is one pair of adjacent vector registers, so that gfx950's packed binary32 instructions (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32: two independent IEEE operations per issue slot) do both components at once.  The arithmetic
+// contract is untouched: every helper below performs exactly the operations, in exactly the roles, of the scalar formulas it
+// replaces (oracle/dab_rx.c has them written out) — the packed forms only choose, with their op_sel / neg modifiers, which
+// half of a pair feeds which half of the result.  k_demod is bound by vector-ALU issue (profiles/r03*): written with scalar
+// components the compiler spent 23 % of the symbol loop on moves and sign flips to line operands up; 509 -> 3xx instructions.
+typedef float cf __attribute__((ext_vector_type(2)));          // .x = real part, .y = imaginary part
 
-// complex products: one rounded product, then one fused multiply-add (2 + 2 instructions instead of 4 + 2) —
+// complex products: one rounded product, then one fused multiply-add per component —
 // the same two operations, in the same roles, in the CPU checker (oracle/dab_rx.c: fmaf)
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
-    const float p1 = a.i * b.i, p3 = a.i * b.r;
-    return {__builtin_fmaf(a.r, b.r, -p1), __builtin_fmaf(a.r, b.i, p3)};
+    cf p, d;      // p = (a.i b.i, a.i b.r);  d = (fma(a.r, b.r, -p.x), fma(a.r, b.i, p.y))
+    // (one asm statement: between two of them the compiler, which cannot see what they hold, puts a wait state)
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(d), "=&v"(p) : "v"(a), "v"(b));
+    return d;
 }
 __device__ __forceinline__ cf cmulc(cf a, cf b)   // a * conj(b)
 {
-    const float p1 = a.i * b.i, p3 = a.r * b.i;
-    return {__builtin_fmaf(a.r, b.r, p1), __builtin_fmaf(a.i, b.r, -p3)};
+    cf p, d;      // p = (a.i b.i, a.r b.i);  d = (fma(a.r, b.r, p.x), fma(a.i, b.r, -p.y))
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(d), "=&v"(p) : "v"(a), "v"(b));
+    return d;
 }
+// a + (-j) b = (a.r + b.i, a.i - b.r) and a - (-j) b = (a.r - b.i, a.i + b.r): one packed add each, the halves of b swapped by
+// op_sel and one of them negated (x + (-y) is x - y in IEEE arithmetic)
+__device__ __forceinline__ cf add_mj(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ cf sub_mj(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ cf rotq(cf x, int q)   // x * exp(-j q pi/2), exact
 {
     switch (q & 3) {
     case 0: return x;
-    case 1: return {x.i, -x.r};
-    case 2: return {-x.r, -x.i};
-    default: return {-x.i, x.r};
+    case 1: return {x.y, -x.x};
+    case 2: return {-x.x, -x.y};
+    default: return {-x.y, x.x};
     }
 }
 
 // ---- 2048-point FFT: radix 8-8-8-4 decimation in frequency, 256 threads, 8 points each.
 __device__ __forceinline__ void r4(cf &u0, cf &u1, cf &u2, cf &u3)
 {
-    cf p0 = {u0.r + u2.r, u0.i + u2.i}, p1 = {u0.r - u2.r, u0.i - u2.i};
-    cf q0 = {u1.r + u3.r, u1.i + u3.i};
-    float tr = u1.r - u3.r, ti = u1.i - u3.i;
-    cf q1 = {ti, -tr};
-    u0 = {p0.r + q0.r, p0.i + q0.i}; u2 = {p0.r - q0.r, p0.i - q0.i};
-    u1 = {p1.r + q1.r, p1.i + q1.i}; u3 = {p1.r - q1.r, p1.i - q1.i};
+    const cf p0 = u0 + u2, p1 = u0 - u2, q0 = u1 + u3, t = u1 - u3;
+    u0 = p0 + q0; u2 = p0 - q0;
+    u1 = add_mj(p1, t); u3 = sub_mj(p1, t);          // p1 +- (-j) t
 }
 __device__ __forceinline__ void r8(cf v[8])
 {
     const float c8 = 0.70710678118654752440f;
-    cf a0 = {v[0].r + v[4].r, v[0].i + v[4].i}, b0 = {v[0].r - v[4].r, v[0].i - v[4].i};
-    cf a1 = {v[1].r + v[5].r, v[1].i + v[5].i}, b1 = {v[1].r - v[5].r, v[1].i - v[5].i};
-    cf a2 = {v[2].r + v[6].r, v[2].i + v[6].i}, b2 = {v[2].r - v[6].r, v[2].i - v[6].i};
-    cf a3 = {v[3].r + v[7].r, v[3].i + v[7].i}, b3 = {v[3].r - v[7].r, v[3].i - v[7].i};
-    float t0, t1;
-    t0 = b1.r + b1.i; t1 = b1.i - b1.r; b1 = {c8 * t0, c8 * t1};
-    b2 = {b2.i, -b2.r};
-    t0 = b3.i - b3.r; t1 = b3.r + b3.i; b3 = {c8 * t0, -(c8 * t1)};
+    cf a0 = v[0] + v[4], b0 = v[0] - v[4], a1 = v[1] + v[5], b1 = v[1] - v[5];
+    cf a2 = v[2] + v[6], b2 = v[2] - v[6], a3 = v[3] + v[7], b3 = v[3] - v[7];
+    // b1 (1 - j) / sqrt 2 = c8 (r + i, i - r);  b3 (-1 - j) / sqrt 2 = (c8 (i - r), -(c8 (r + i)))
+    b1 = (cf){c8, c8} * add_mj(b1, b1);
+    { const cf m = sub_mj(b3, b3); b3 = (cf){c8, c8} * (cf){-m.x, -m.y}; }        // m = (r - i, i + r)
     r4(a0, a1, a2, a3);
-    r4(b0, b1, b2, b3);
+    // r4 of (b0, b1, (-j) b2, b3) with the rotation of b2 folded into its first butterflies
+    const cf p0 = add_mj(b0, b2), p1 = sub_mj(b0, b2), q0 = b1 + b3, t = b1 - b3;
     v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
-    v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+    v[1] = p0 + q0; v[5] = p0 - q0;
+    v[3] = add_mj(p1, t); v[7] = sub_mj(p1, t);
 }
 
 // LDS index with four pad slots (32 bytes) per 32 complex values: rows of the stride-4 pass
@@ -128,7 +139,7 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
 #pragma unroll
     for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], twa[c - 1]);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) buf[pad(t + 256 * c)] = make_float2(v[c].r, v[c].i);
+    for (int c = 0; c < 8; ++c) buf[pad(t + 256 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
     int base = (t >> 5) * 256 + (t & 31);
 #pragma unroll
@@ -136,11 +147,11 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
     r8(v);
 #pragma unroll
     for (int c = 1; c < 8; ++c) {
-        if (twl) { float2 w = twl[(t & 31) * 7 + c - 1]; v[c] = cmul(v[c], {w.x, w.y}); }
+        if (twl) { float2 w = twl[(t & 31) * 7 + c - 1]; v[c] = cmul(v[c], (cf){w.x, w.y}); }
         else v[c] = cmul(v[c], twb[c - 1]);
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) buf[pad(base + 32 * c)] = make_float2(v[c].r, v[c].i);
+    for (int c = 0; c < 8; ++c) buf[pad(base + 32 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
     base = (t >> 2) * 32 + (t & 3);
 #pragma unroll
@@ -148,11 +159,11 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
     r8(v);
 #pragma unroll
     for (int c = 1; c < 8; ++c) {
-        if (twl) { float2 w = twl[7 * 32 + (t & 3) * 7 + c - 1]; v[c] = cmul(v[c], {w.x, w.y}); }
+        if (twl) { float2 w = twl[7 * 32 + (t & 3) * 7 + c - 1]; v[c] = cmul(v[c], (cf){w.x, w.y}); }
         else v[c] = cmul(v[c], twc[c - 1]);
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].r, v[c].i);
+    for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
     {   // positions 8t .. 8t+7 are contiguous (never across a pad): four 16-byte reads, conflict-free per 8 lanes
         const float4 *p = reinterpret_cast<const float4 *>(buf + pad(8 * t));
@@ -208,7 +219,7 @@ __device__ __forceinline__ float reduce256(float x, float *red /*4 floats*/, int
 __device__ __forceinline__ cf nco(const DevTables &T, uint32_t th)
 {
     float2 h = T.nco_hi[th >> 21], l = T.nco_lo[(th >> 10) & 2047];
-    return cmul({h.x, h.y}, {l.x, l.y});
+    return cmul((cf){h.x, h.y}, (cf){l.x, l.y});
 }
 
 template <int FMT>
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     if (wide) {
         // spectrum to natural order for the shifted differential correlation
 #pragma unroll
-        for (int e = 0; e < 8; ++e) nat[T.bin_of_pos[8 * t + e]] = make_float2(v[e].r, v[e].i);
+        for (int e = 0; e < 8; ++e) nat[T.bin_of_pos[8 * t + e]] = make_float2(v[e].x, v[e].y);
         __syncthreads();
         float best = -1.0f;
         for (int m = -CFO_RANGE; m <= CFO_RANGE; ++m) {
@@ -473,9 +484,9 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
                 if (j >= 1534) break;
                 int k = T.cfo_car[j];
                 float2 x1 = nat[(k + m) & 2047], x0 = nat[(k + m - 1) & 2047];
-                cf d = cmulc({x1.x, x1.y}, {x0.x, x0.y});
+                cf d = cmulc((cf){x1.x, x1.y}, (cf){x0.x, x0.y});
                 cf e = rotq(d, T.prs_dq[k & 2047]);
-                ar = ar + e.r; ai = ai + e.i;
+                ar = ar + e.x; ai = ai + e.y;
             }
             float cr = reduce256(ar, red, t);
             float ci = reduce256(ai, red, t);
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     if (C.spectrum && f == n_frames - 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float a = v[e].r * v[e].r, b = v[e].i * v[e].i;
+            float a = v[e].x * v[e].x, b = v[e].y * v[e].y;
             C.spectrum[(size_t)s * TU + T.bin_of_pos[8 * t + e]] = a + b;
         }
     }
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
         int q = T.prs_q[b];
         cf r = {0.0f, 0.0f};
         if (q >= 0) r = rotq(v[e], q);
-        nat[b] = make_float2(r.r, -r.i);
+        nat[b] = make_float2(r.x, -r.y);
     }
     __syncthreads();
 #pragma unroll
@@ -515,7 +526,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     int pidx = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float a = v[e].r * v[e].r, b = v[e].i * v[e].i, m2 = a + b;
+        float a = v[e].x * v[e].x, b = v[e].y * v[e].y, m2 = a + b;
         acc = acc + m2;
         int n = T.bin_of_pos[8 * t + e];
         if (m2 > peak || (m2 == peak && n < pidx)) { peak = m2; pidx = n; }
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int d = (pidx - T.bin_of_pos[8 * t + e]) & 2047;
-            const float a = v[e].r * v[e].r, b = v[e].i * v[e].i, m2 = a + b;
+            const float a = v[e].x * v[e].x, b = v[e].y * v[e].y, m2 = a + b;
             if (d != 0 && d <= EARLY_SPAN && m2 >= thr && d > dmax) dmax = d;
         }
 #pragma unroll
@@ -578,7 +589,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
         fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float a = v[e].r * v[e].r, b = v[e].i * v[e].i;
+            float a = v[e].x * v[e].x, b = v[e].y * v[e].y;
             C.null_spectrum[((size_t)s * C.max_frames + f) * TU + T.bin_of_pos[8 * t + e]] = a + b;
         }
     }
@@ -644,11 +655,11 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
         const int32_t dth = (int32_t)(((int64_t)slope * 319) / 768);
         const int m_e[8] = {0, 512, -1024, -512, 64, 576, -960, -448};
         const cf rt = nco(T, (uint32_t)(((t >> 5) + 8 * ((t >> 2) & 7) + 128 * (t & 3)) * dth));
-        rt_l[t] = make_float2(rt.r, rt.i);                       // read back by the same thread only
+        rt_l[t] = make_float2(rt.x, rt.y);                       // read back by the same thread only
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const cf x = nco(T, (uint32_t)(m_e[e] * dth));
-            sm[e] = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x.r))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x.i)))};
+            sm[e] = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x.y)))};
         }
     }
 
@@ -676,8 +687,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 y[e] = cmulc(v[e], prev[e]);
-                if constexpr (SCO) { const float2 r = rt_l[t]; y[e] = cmul(cmul(y[e], sm[e]), {r.x, r.y}); }
-                const float a = fabsf(y[e].r) + fabsf(y[e].i);
+                if constexpr (SCO) { const float2 r = rt_l[t]; y[e] = cmul(cmul(y[e], sm[e]), (cf){r.x, r.y}); }
+                const float a = fabsf(y[e].x) + fabsf(y[e].y);
                 acc = acc + ((used >> e) & 1u ? a : 0.0f);               // adding +0 leaves the sum as it is
             }
             float S = reduce256(acc, red, t), gsc = 0.0f;
@@ -686,8 +697,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             for (int e = 0; e < 8; ++e) {
                 // rint(y * gsc) clamped to +-31: gsc is a power of two, so the product is exact and adding 1.5 * 2^23 rounds it
                 // to the nearest integer (ties to even) into the low bits of the float — the same value as rintf(), one FMA
-                const int a = __float_as_int(__builtin_fmaf(y[e].r, gsc, 12582912.0f)) - 0x4B400000;
-                const int b = __float_as_int(__builtin_fmaf(y[e].i, gsc, 12582912.0f)) - 0x4B400000;
+                const int a = __float_as_int(__builtin_fmaf(y[e].x, gsc, 12582912.0f)) - 0x4B400000;
+                const int b = __float_as_int(__builtin_fmaf(y[e].y, gsc, 12582912.0f)) - 0x4B400000;
                 const int qa = min(max(a, -(int)SOFT_MAX), (int)SOFT_MAX), qb = min(max(b, -(int)SOFT_MAX), (int)SOFT_MAX);
                 soft[nidx[e]] = (uint16_t)((qa & 0xff) | ((qb & 0xff) << 8));
             }
@@ -1115,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_fft(DevTables T, const float2 *in, floa
     cf v[8];
     for (int j = 0; j < 8; ++j) { float2 x = in[(size_t)blockIdx.x * TU + t + 256 * j]; v[j] = {x.x, x.y}; }
     fft2048(v, buf, t, tw);
-    for (int e = 0; e < 8; ++e) out[(size_t)blockIdx.x * TU + T.bin_of_pos[8 * t + e]] = make_float2(v[e].r, v[e].i);
+    for (int e = 0; e < 8; ++e) out[(size_t)blockIdx.x * TU + T.bin_of_pos[8 * t + e]] = make_float2(v[e].x, v[e].y);
 }
 
 // ----------------------------------------------------------------------- finish
