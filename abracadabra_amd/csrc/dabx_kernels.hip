@@ -66,6 +66,34 @@ __device__ __forceinline__ cf cmulc(cf a, cf b)   // a * conj(b)
 // op_sel and one of them negated (x + (-y) is x - y in IEEE arithmetic)
 __device__ __forceinline__ cf add_mj(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ cf sub_mj(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#include "dabx_cplx.inc"
+// v[1..7] *= w[0..6] (the twiddles of one FFT pass) as one asm statement
+__device__ __forceinline__ void cmul7(cf v[8], const cf w[7])
+{
+    cf p, q;
+    asm(DABX_CMUL7_INPLACE
+        : [v0] "+v"(v[1]), [v1] "+v"(v[2]), [v2] "+v"(v[3]), [v3] "+v"(v[4]), [v4] "+v"(v[5]), [v5] "+v"(v[6]), [v6] "+v"(v[7]), [p] "=&v"(p), [q] "=&v"(q)
+        : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]));
+}
+// y[e] = a[e] conj(b[e]), e < 8
+__device__ __forceinline__ void cmulc8(cf y[8], const cf a[8], const cf b[8])
+{
+    cf p, q;
+    asm(DABX_CMULC8
+        : [y0] "=&v"(y[0]), [y1] "=&v"(y[1]), [y2] "=&v"(y[2]), [y3] "=&v"(y[3]), [y4] "=&v"(y[4]), [y5] "=&v"(y[5]), [y6] "=&v"(y[6]), [y7] "=&v"(y[7]),
+          [p] "=&v"(p), [q] "=&v"(q)
+        : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),
+          [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]), [b7] "v"(b[7]));
+}
+// x[j] = x[j] rot_j with rot_0 = rot, rot_j = rot_{j-1} step (the window's de-rotation: a recurrence over the eight samples of a thread)
+__device__ __forceinline__ void derotate8(cf x[8], cf rot, cf step)
+{
+    cf p, q;
+    asm(DABX_DEROTATE8
+        : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), [x6] "+v"(x[6]), [x7] "+v"(x[7]),
+          [rot] "+v"(rot), [p] "=&v"(p), [q] "=&v"(q)
+        : [step] "v"(step));
+}
 __device__ __forceinline__ cf rotq(cf x, int q)   // x * exp(-j q pi/2), exact
 {
     switch (q & 3) {
@@ -136,8 +164,7 @@ template <bool SYNC = true>
 __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const cf *twa, const cf *twb, const cf *twc, const float2 *twl)
 {
     r8(v);
-#pragma unroll
-    for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], twa[c - 1]);
+    cmul7(v, twa);
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(t + 256 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
@@ -145,11 +172,12 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 32 * j)]; v[j] = {x.x, x.y}; }
     r8(v);
+    if (twl) {
+        cf w[7];
 #pragma unroll
-    for (int c = 1; c < 8; ++c) {
-        if (twl) { float2 w = twl[(t & 31) * 7 + c - 1]; v[c] = cmul(v[c], (cf){w.x, w.y}); }
-        else v[c] = cmul(v[c], twb[c - 1]);
-    }
+        for (int c = 0; c < 7; ++c) { const float2 x = twl[(t & 31) * 7 + c]; w[c] = {x.x, x.y}; }
+        cmul7(v, w);
+    } else cmul7(v, twb);
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 32 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
@@ -157,11 +185,12 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 4 * j)]; v[j] = {x.x, x.y}; }
     r8(v);
+    if (twl) {
+        cf w[7];
 #pragma unroll
-    for (int c = 1; c < 8; ++c) {
-        if (twl) { float2 w = twl[7 * 32 + (t & 3) * 7 + c - 1]; v[c] = cmul(v[c], (cf){w.x, w.y}); }
-        else v[c] = cmul(v[c], twc[c - 1]);
-    }
+        for (int c = 0; c < 7; ++c) { const float2 x = twl[7 * 32 + (t & 3) * 7 + c]; w[c] = {x.x, x.y}; }
+        cmul7(v, w);
+    } else cmul7(v, twc);
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
@@ -241,7 +270,11 @@ __device__ __forceinline__ cf sample_f(const uint8_t *ring, uint32_t idx)
 {
     if (FMT == 0) {
         const uint32_t u = reinterpret_cast<const uint16_t *>(ring)[idx];
-        return {(float)(u & 0xffu) - 128.0f, (float)(u >> 8) - 128.0f};          // v_cvt_f32_ubyte0 / ubyte1 + one subtraction
+        // v_cvt_f32_ubyte0 / ubyte1 straight from the loaded pair, then ONE packed subtraction (written out: left to itself the
+        // compiler subtracts in the integer domain first — exact as well, but two byte extractions and two adds more per sample)
+        float a, b;
+        asm("v_cvt_f32_ubyte0 %0, %2\n\tv_cvt_f32_ubyte1 %1, %2" : "=&v"(a), "=v"(b) : "v"(u));      // (a must not share u's register: u is read again)
+        return (cf){a, b} + (cf){-128.0f, -128.0f};
     }
     const uint32_t u = reinterpret_cast<const uint32_t *>(ring)[idx];
     return {(float)(int16_t)(u & 0xffff), (float)(int16_t)(u >> 16)};
@@ -259,19 +292,14 @@ __device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const u
     const cf step = nco(T, dth * 256u);
     cf rot = nco(T, dth * (phase_off + (uint32_t)t));
     const uint8_t *base = ring + widx * (FMT == 0 ? 2 : 4);                      // uniform: scalar registers
-    cf x[8];
 #pragma unroll
 #ifdef DABX_PROBE_NOLOAD
-    for (int j = 0; j < 8; ++j) x[j] = {(float)((t + 7 * j) & 31) - 16.0f, (float)((t * 3 + j) & 31) - 16.0f};   // timing probe: no memory
+    for (int j = 0; j < 8; ++j) v[j] = {(float)((t + 7 * j) & 31) - 16.0f, (float)((t * 3 + j) & 31) - 16.0f};   // timing probe: no memory
     (void)base;
 #else
-    for (int j = 0; j < 8; ++j) x[j] = sample_f<FMT>(base, (uint32_t)(t + 256 * j));
+    for (int j = 0; j < 8; ++j) v[j] = sample_f<FMT>(base, (uint32_t)(t + 256 * j));
 #endif
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j) rot = cmul(rot, step);
-        v[j] = cmul(x[j], rot);
-    }
+    derotate8(v, rot, step);                     // v[j] = cmul(x[j], rot_j), rot_j = cmul(rot_{j-1}, step)
 }
 
 // integer CORDIC, angle of (x + j y) in 2^-32 turns
@@ -684,9 +712,9 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             const int16_t *tab = dst_l[l <= 3 ? 0 : 1];
 #pragma unroll
             for (int e = 0; e < 8; ++e) nidx[e] = tab[8 * t + e];
+            cmulc8(y, v, prev);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                y[e] = cmulc(v[e], prev[e]);
                 if constexpr (SCO) { const float2 r = rt_l[t]; y[e] = cmul(cmul(y[e], sm[e]), (cf){r.x, r.y}); }
                 const float a = fabsf(y[e].x) + fabsf(y[e].y);
                 acc = acc + ((used >> e) & 1u ? a : 0.0f);               // adding +0 leaves the sum as it is
@@ -696,11 +724,13 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 // rint(y * gsc) clamped to +-31: gsc is a power of two, so the product is exact and adding 1.5 * 2^23 rounds it
-                // to the nearest integer (ties to even) into the low bits of the float — the same value as rintf(), one FMA
-                const int a = __float_as_int(__builtin_fmaf(y[e].x, gsc, 12582912.0f)) - 0x4B400000;
-                const int b = __float_as_int(__builtin_fmaf(y[e].y, gsc, 12582912.0f)) - 0x4B400000;
-                const int qa = min(max(a, -(int)SOFT_MAX), (int)SOFT_MAX), qb = min(max(b, -(int)SOFT_MAX), (int)SOFT_MAX);
-                soft[nidx[e]] = (uint16_t)((qa & 0xff) | ((qb & 0xff) << 8));
+                // to the nearest integer (ties to even) into the low bits of the float — the same value as rintf(), one (packed)
+                // FMA for both components.  The bit pattern is 0x4B400000 + n: clamped as an integer between 0x4B400000 -+ 31 its
+                // low byte IS the soft bit (two's complement), so no subtraction and no masking: one byte permute packs the pair.
+                const cf tq = __builtin_elementwise_fma(y[e], (cf){gsc, gsc}, (cf){12582912.0f, 12582912.0f});
+                const int lo = 0x4B400000 - (int)SOFT_MAX, hi = 0x4B400000 + (int)SOFT_MAX;
+                const int qa = min(max(__float_as_int(tq.x), lo), hi), qb = min(max(__float_as_int(tq.y), lo), hi);
+                soft[nidx[e]] = (uint16_t)__builtin_amdgcn_perm((uint32_t)qb, (uint32_t)qa, 0x0c0c0400u);
             }
             __syncthreads();
             if (t < NCAR / 16) {
