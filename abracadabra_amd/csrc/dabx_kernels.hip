@@ -185,12 +185,13 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { float2 x = buf[pad(base + 4 * j)]; v[j] = {x.x, x.y}; }
     r8(v);
-    if (twl) {
+    if (twc) cmul7(v, twc);                          // (registers win over the LDS table when both are given)
+    else {
         cf w[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c) { const float2 x = twl[7 * 32 + (t & 3) * 7 + c]; w[c] = {x.x, x.y}; }
         cmul7(v, w);
-    } else cmul7(v, twc);
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].x, v[c].y);
     if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
@@ -650,8 +651,10 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     const int64_t cif0 = st.cif + 4 * (int64_t)f;
 
     __shared__ float2 twl[TWL];
-    cf twa[7];
+    cf twa[7], twc[7];                                           // passes A and C: registers; pass B: the LDS table (the registers end here)
     load_twiddles_lds(twa, twl, T.W, t);
+#pragma unroll
+    for (int c = 1; c < 8; ++c) { const float2 z = T.W[64 * (t & 3) * c]; twc[c - 1] = {z.x, z.y}; }
 #ifdef DABX_PROBE_STAGGER
     // timing probe: workgroups in odd slots of their CU (HW_ID.TG_ID) start late, so that their LDS phases meet the others' VALU phases
     if ((__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 1)) __builtin_amdgcn_s_sleep(DABX_PROBE_STAGGER);
@@ -659,14 +662,14 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     // where the soft-bit pair of each FFT output position goes in the staging buffer: the frequency de-interleaver index n
     // itself for FIC symbols ([0]), its residue-major place (n & 15) * 96 + (n >> 4) for MSC symbols ([1]); the bins
     // outside the 1536 carriers go to a dummy slot of the lane (no branch around the store), used[] masks them out of the sum
-    __shared__ int16_t dst_l[2][TU];
+    __shared__ __attribute__((aligned(16))) uint16_t dst_l[2][TU];         // BYTE offsets into soft[] (2 x the index): one 16-byte read per symbol and thread
     uint32_t used = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int n = T.n_of_bin[T.bin_of_pos[8 * t + e]];
         used |= (n >= 0 ? 1u : 0u) << e;
-        dst_l[0][8 * t + e] = static_cast<int16_t>(n < 0 ? NCAR + (t & 63) : n);
-        dst_l[1][8 * t + e] = static_cast<int16_t>(n < 0 ? NCAR + (t & 63) : (n & 15) * (NCAR / 16) + (n >> 4));
+        dst_l[0][8 * t + e] = static_cast<uint16_t>(2 * (n < 0 ? NCAR + (t & 63) : n));
+        dst_l[1][8 * t + e] = static_cast<uint16_t>(2 * (n < 0 ? NCAR + (t & 63) : (n & 15) * (NCAR / 16) + (n >> 4)));
     }
 
     // Sampling-clock offset: the windows keep their nominal spacing, so a recording whose clock is off by eps sees every
@@ -701,17 +704,15 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
         widx += TS;
         if (widx >= C.ring_len) widx -= C.ring_len;
 #ifdef DABX_PROBE_DEMOD_NOBARRIER
-        fft2048_core<false>(v, buf, t, twa, nullptr, nullptr, twl);
+        fft2048_core<false>(v, buf, t, twa, nullptr, twc, twl);
 #else
-        fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
+        fft2048_core(v, buf, t, twa, nullptr, twc, twl);
 #endif
         if (l > l_ref) {
             cf y[8];
-            int nidx[8];
             float acc = 0.0f;
-            const int16_t *tab = dst_l[l <= 3 ? 0 : 1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) nidx[e] = tab[8 * t + e];
+            const uint4 nidx4 = *reinterpret_cast<const uint4 *>(dst_l[l <= 3 ? 0 : 1] + 8 * t);      // eight byte offsets, two per dword
+            const uint32_t nidx2[4] = {nidx4.x, nidx4.y, nidx4.z, nidx4.w};
             cmulc8(y, v, prev);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -730,7 +731,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
                 const cf tq = __builtin_elementwise_fma(y[e], (cf){gsc, gsc}, (cf){12582912.0f, 12582912.0f});
                 const int lo = 0x4B400000 - (int)SOFT_MAX, hi = 0x4B400000 + (int)SOFT_MAX;
                 const int qa = min(max(__float_as_int(tq.x), lo), hi), qb = min(max(__float_as_int(tq.y), lo), hi);
-                soft[nidx[e]] = (uint16_t)__builtin_amdgcn_perm((uint32_t)qb, (uint32_t)qa, 0x0c0c0400u);
+                const uint32_t off = (e & 1) ? nidx2[e >> 1] >> 16 : nidx2[e >> 1] & 0xffffu;
+                *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(soft) + off) = (uint16_t)__builtin_amdgcn_perm((uint32_t)qb, (uint32_t)qa, 0x0c0c0400u);
             }
             __syncthreads();
             if (t < NCAR / 16) {
