@@ -370,14 +370,16 @@ def legacy_leg(args):
     the shape of BASELINE configs[0] / [2].  Both legs must decode without a FIB error; the service leg without an AU CRC error."""
     from tools import legacy_bench
     try:
-        r = legacy_bench.run(frames=args.legacy_frames)
+        r = legacy_bench.run(frames=args.legacy_frames, long_codewords=True)
     except Exception as e:                                    # noqa: BLE001 — reported in the line, and the run fails
         return {"ok": False, "error": repr(e)}
     fic, svc = r.get("fic_only", {}), r.get("one_service_48cu", {})
     ok = (fic.get("rc") == 0 and svc.get("rc") == 0 and fic.get("fib_errors") == 0 and svc.get("fib_errors") == 0 and fic.get("sync_level") == 3
           and svc.get("access_units", 0) > 0 and svc.get("au_crc_err") == 0 and svc.get("au_concealed") == 0)
+    big = r.get("one_service_416cu_mp2", {})
+    ok = ok and big.get("rc") == 0 and big.get("fib_errors") == 0 and big.get("access_units", 0) > 0
     return {"unit": "x real-time, one ensemble, un-paced float input callback (dabsdr.h:387), all notifications and audio callbacks delivered",
-            "fic_only": fic, "one_service_48cu": svc, "ok": bool(ok),
+            "fic_only": fic, "one_service_48cu": svc, "one_service_416cu_mp2": big, "ok": bool(ok),
             "reference_binary_one_cpu_thread": {"fic_only": "188-195", "one_service_48cu": "105-110", "source": "SURVEY.md §6 (measured by the survey session; not run here)"}}
 
 

@@ -27,23 +27,33 @@ def build_tool(out_dir):
     return exe
 
 
-def make_signal(path, snr_db=25.0, seed=5):
+def make_signal(path, snr_db=25.0, seed=5, big=False):
     import numpy as np
     from oracle import binding as ob
-    sub = [[0, 0, 3, 64]]                                   # 48 CU, EEP 3-A, 64 kbit/s, DAB+ (FIG 0/2 ASCTy 63)
-    rows, _ = ob.superframes(64, 16, seed=seed)             # 80 logical frames
+    if big:                                                 # 416 CU, UEP table index 63 (384 kbit/s, level 1), MPEG Layer II (ASCTy 0):
+        sub, rows = [[0, 2, 63, 0]], None                   # codewords of 9 222 trellis steps, the longest audio sub-channel there is
+    else:
+        sub = [[0, 0, 3, 64]]                               # 48 CU, EEP 3-A, 64 kbit/s, DAB+ (FIG 0/2 ASCTy 63)
+        rows, _ = ob.superframes(64, 16, seed=seed)         # 80 logical frames
     iq, _, _ = ob.tx_generate(seed=seed, eid=0x1234, n_frames=20, subch=sub, loop=1, snr_db=snr_db, payload=rows)
     np.asarray(iq, dtype=np.uint8).tofile(path)
 
 
-def run(frames=3000, timeout=120):
-    """Both legs; returns {"fic_only": {...}, "one_service_48cu": {...}} (the tool's JSON lines)."""
+def run(frames=3000, timeout=120, long_codewords=False):
+    """Both legs; returns {"fic_only": {...}, "one_service_48cu": {...}} (the tool's JSON lines).
+    long_codewords: a third leg with one 416-CU MPEG Layer II service (9 222 trellis steps per codeword): is the
+    one-wave-per-codeword Viterbi decoder the limit of a single ensemble?"""
     out = {}
     with tempfile.TemporaryDirectory() as d:
         exe = build_tool(d)
         sig = os.path.join(d, "periodic.u8")
         make_signal(sig)
-        for name, extra in (("fic_only", []), ("one_service_48cu", [hex(SID)])):
+        legs = [("fic_only", [], sig), ("one_service_48cu", [hex(SID)], sig)]
+        if long_codewords:
+            big = os.path.join(d, "periodic_big.u8")
+            make_signal(big, big=True)
+            legs.append(("one_service_416cu_mp2", [hex(SID)], big))
+        for name, extra, sig in legs:
             p = subprocess.run([exe, sig, str(frames)] + extra, capture_output=True, text=True, timeout=timeout)
             line = (p.stdout.strip().splitlines() or ["{}"])[-1]
             try:
@@ -55,4 +65,4 @@ def run(frames=3000, timeout=120):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 3000), indent=1))
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 3000, long_codewords="--long" in sys.argv), indent=1))
