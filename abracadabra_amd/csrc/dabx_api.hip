@@ -860,8 +860,11 @@ int dabx_wait(dabx_ctx *c)
     std::lock_guard<std::mutex> lk(c->mu);
     (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     if (!c->pending) return DABX_OK;
-    c->pending = false;                              // also when the synchronisation fails: the context stays usable
+    c->pending = false;                              // also when the synchronisation fails: the context stays usable ...
+    const bool mirror = c->res_valid;
+    c->res_valid = false;                            // ... but the result mirror holds nothing then: the getters go to the device (and fail there)
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->res_valid = mirror;
     for (int s = 0; s < c->cfg.n_streams; ++s) c->streams[s].st = c->h_state[s];
     if (c->timing) {
         HIPCHK(hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[1]));

@@ -825,17 +825,12 @@ __device__ __forceinline__ uint32_t soft_tab_entry(const VitSrc &src, uint32_t k
     return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(k, (uint32_t)TI_SEG) + wrap;
 }
 
-// depuncturing word of trellis step tau; the table ends with a zero word (dabx_spec.hpp: step_info), which the steps past the
-// end read: no branch, and a scalar base + 32-bit offset as the address
-__device__ __forceinline__ uint32_t step_word(const uint32_t *__restrict__ info, uint32_t tau, uint32_t nsteps)
-{
-    const uint32_t off = (tau < nsteps ? tau : nsteps) * 4u;
-    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(info) + off);
-}
-// The soft values of the step described by w as the A row the matrix core wants: (2 x0, 2 x1, 2 x2, 2 x3), one byte each,
-// zero where punctured (|x| <= 31, so twice a value fits its byte).  A step keeps a prefix of its four bits (dabx_spec.hpp:
-// step_info), so the four bytes at the step's offset are loaded unconditionally (issued together, no branch, valid addresses:
+// The soft values of the step described by the depuncturing word w (dabx_spec.hpp: step_info) as the A row the matrix core wants:
+// (2 x0, 2 x1, 2 x2, 2 x3), one byte each, zero where punctured (|x| <= 31, so twice a value fits its byte).  A step keeps a prefix
+// of its four bits, so the four bytes at the step's offset are loaded unconditionally (issued together, no branch, valid addresses:
 // the buffers carry slack), shifted left by one inside their bytes, and the punctured ones are masked off.
+// (d16 byte loads that would drop the bytes into the halves of two registers were tried: on a GPU with SRAM ECC — this one — a d16
+// load clears the other half of its destination, so the bytes still have to be collected by instructions.)
 __device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
 {
     const uint32_t i0 = w >> 5;
@@ -1010,7 +1005,10 @@ __device__ bool viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     // Soft-bit pipeline, three blocks of 48 steps deep: the depuncturing words of block b+2 and
     // the soft bytes of block b+1 are in flight while block b runs, so each of the two
     // dependent loads has a whole block of ACS work to hide behind.
-    const int tl = lane < VIT_BLK ? lane : (1 << 28);            // lanes 48..63 fetch nothing
+    // byte offset of the lane's next depuncturing word: step lane, then 48 further per block; lanes 48..63 fetch nothing — they
+    // read one of the zero words behind the table and stay there (the tables carry kStepInfoPad of them: no clamping)
+    uint32_t toff = 4u * (uint32_t)(lane < VIT_BLK ? lane : nsteps + lane);
+    const uint32_t tinc = lane < VIT_BLK ? 4u * VIT_BLK : 0u;
     // A row of this lane: row r = the step of group r of a 24-step chunk (LDS byte address: the low 32 bits of a shared
     // pointer); the four addresses of a read (rows 0..3: six dwords apart) fall into four different LDS banks
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);
@@ -1018,17 +1016,19 @@ __device__ bool viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // LDS byte address of the wave's decision ring
     const int sh = src.slot_mask < 0 ? 4 : 0;
     if (lane < 19) xs[64 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
-    int xa = gather_step(src, tab, sh, step_word(info, tl, nsteps));
-    uint32_t wnext = step_word(info, VIT_BLK + tl, nsteps);
-    uint32_t tau_fetch = 2 * VIT_BLK + (uint32_t)tl;             // the step whose depuncturing word this lane loads next
+    const char *infob = reinterpret_cast<const char *>(info);
+    int xa = gather_step(src, tab, sh, *reinterpret_cast<const uint32_t *>(infob + toff));
+    toff += tinc;
+    uint32_t wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
+    toff += tinc;                                                // (the word this lane loads next)
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
         xs[lane] = xa;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
                                                                  // operations execute in order, the previous block's reads are done
 #ifndef DABX_PROBE_NOGATHER
         xa = gather_step(src, tab, sh, wnext);
-        wnext = step_word(info, tau_fetch, nsteps);
-        tau_fetch += VIT_BLK;
+        wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
+        toff += tinc;
 #endif
         const uint32_t va = va0;
         uint32_t bits = 0;

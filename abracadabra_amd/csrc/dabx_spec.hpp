@@ -209,10 +209,11 @@ inline bool any_profile(int option, int level, int kbps, Profile &p)
 // puncturing vector of EN 300 401 table 29 keeps a PREFIX of the four mother-code bits of a step (1000, 1100, 1110 or
 // 1111), so the kept soft bits are the next `ones` bits of the stream and the low field is the right shift that turns
 // 0xFFFFFFFF into their byte mask.
+constexpr int kStepInfoPad = 256;
 inline std::vector<uint32_t> step_info(const Profile &p)
 {
     std::vector<uint32_t> info;
-    info.reserve(p.steps() + 1);
+    info.reserve(p.steps() + kStepInfoPad);
     uint32_t off = 0;
     auto emit = [&](int ones) {
         info.push_back((off << 5) | static_cast<uint32_t>(8 * (4 - ones)));
@@ -222,7 +223,9 @@ inline std::vector<uint32_t> step_info(const Profile &p)
         for (int blk = 0; blk < p.L[s]; ++blk)
             for (int g = 0; g < 32; ++g) emit(punct_group_ones(p.PI[s], g & 7));
     for (int g = 0; g < 6; ++g) emit(2);
-    info.push_back(0);                       // word [steps()]: what k_viterbi's fetch reads for a step past the end (nothing to load)
+    // words [steps() ..]: what k_viterbi's fetch reads for the steps past the end (its fetch runs up to three blocks of 48 ahead and
+    // does not clamp its index; the lanes without a step to fetch read word steps() + lane): nothing to load
+    info.insert(info.end(), kStepInfoPad, 0u);
     return info;
 }
 
