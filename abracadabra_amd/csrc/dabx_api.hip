@@ -11,6 +11,7 @@
 #include "../../include/dabx.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,7 @@ struct StreamHost {
     int msc_bytes = 0;
     uint64_t dabplus = 0;                   // bit k: sub-channel k carries DAB+ audio (dabx_set_dabplus)
     float rs_mu = 0.0f;                     // Farrow resampler: fractional interval after the last input sample
+    bool level_on = false;                  // dabx_enable_level: the converters also run the reference's signal-level detector
 };
 
 }  // namespace
@@ -672,6 +674,14 @@ int64_t dabx_push_resampled_from(dabx_ctx *c, int s, const void *src, int64_t n,
         sh.rs_mu = m;
         }
     }
+    if (sh.level_on) {
+        // the reference's level detector over the INPUT samples (inputdevicesrc.cpp:167-173 / 282-292 / 330-341); constants as its
+        // constructors form them (:84-85, :206-207, :316-317)
+        const double base_rate = (copy || ds2) ? 2048e3 : static_cast<double>(static_cast<float>(in_rate_hz));
+        const float catt = static_cast<float>(1 - std::exp(-1 / (5e-5 * base_rate))), crel = static_cast<float>(1 - std::exp(-1 / (5e-2 * base_rate)));
+        if (src_fmt == DABX_FMT_S16) hipLaunchKernelGGL(rs::k_level<1>, dim3(1), dim3(64), 0, q, in, n, ds2 ? 1 : 0, ds2 ? 2 : 1, catt, crel, st);
+        else hipLaunchKernelGGL(rs::k_level<2>, dim3(1), dim3(64), 0, q, in, n, ds2 ? 1 : 0, ds2 ? 2 : 1, catt, crel, st);
+    }
     HIPCHK(hipGetLastError());
     if (async) c->copies_queued = true;                  // the next step waits for the copy stream
     else HIPCHK(hipStreamSynchronize(q));                // the caller may reuse its buffer
@@ -682,6 +692,34 @@ int64_t dabx_push_resampled_from(dabx_ctx *c, int s, const void *src, int64_t n,
 int64_t dabx_push_resampled(dabx_ctx *c, int s, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain)
 {
     return dabx_push_resampled_from(c, s, src, n, src_fmt, in_rate_hz, gain, DABX_SRC_HOST);
+}
+
+int dabx_enable_level(dabx_ctx *c, int s, int on)
+{
+    if (!valid_stream(c, s)) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    auto &sh = c->streams[s];
+    if (c->d_rs_state && (on != 0) != sh.level_on) {             // switching it starts from level 0, like resetSignalLevel()
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemset(reinterpret_cast<char *>(c->d_rs_state + s) + offsetof(rs::State, level), 0, sizeof(float)));
+    }
+    sh.level_on = on != 0;
+    return DABX_OK;
+}
+
+int dabx_get_level(dabx_ctx *c, int s, float *level)
+{
+    if (!valid_stream(c, s) || !level) return DABX_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->cfg.device);
+    *level = 0.0f;
+    if (!c->d_rs_state) return DABX_OK;
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(level, reinterpret_cast<const char *>(c->d_rs_state + s) + offsetof(rs::State, level), sizeof(float), hipMemcpyDeviceToHost));
+    return DABX_OK;
 }
 
 int dabx_get_input_peak(dabx_ctx *c, int s, int32_t *peak)

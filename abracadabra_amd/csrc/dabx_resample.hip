@@ -8,7 +8,7 @@
 // writing s16 IQ straight into the stream's ring.  Same float operations in the same order as the cited lines
 // (one binary32 operation per step, no contraction), so the results equal the CPU checker (oracle/dab_src.c)
 // bit for bit.  The reference's signal-level detector (a serial attack/release recursion used for device gain
-// control) is not part of the decode path and is not computed here.
+// control) is not part of the decode path; k_level runs it when the caller asks for it (dabx_enable_level).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,6 +34,8 @@ struct State {                       // per stream, device memory
     float2 ds2_hist[DS2_HIST];       // the 42 input samples before the next one, oldest first
     float2 fw_x[FW_M];               // Farrow: integrators of the segment in progress
     float2 fw_a[FW_N - 1][FW_N];     // Farrow: polynomial outputs A_n of the last five finished segments, oldest first
+    float level;                     // signal level (k_level), when the caller asked for it
+    float pad;
 };
 
 template <int FMT>                   // 1: s16 pairs, 2: float pairs
@@ -231,6 +233,41 @@ __global__ void k_farrow_open(const void *in, const int32_t *seg, const float *m
     }
 #pragma unroll
     for (int m = 0; m < FW_M; ++m) x_open[m] = x[m];
+}
+
+// The converters' signal level output (device gain control of the reference's SDR inputs: inputdevicesrc.h:60-75): a rectifier with
+// fast attack and slow release on |x|^2 of the INPUT samples — every sample (Farrow inputdevicesrc.cpp:282-292, pass-through :330-341) or
+// every second one (half-band :154-173: the odd samples) —
+//     c = |x|^2 > level ? c_attack : c_release;   level = (c |x|^2 + level) - c level
+// in binary32, each operation rounded: a serial recursion whose every step depends on the one before, so ONE wave runs it: its
+// lanes square 64 samples at a time, then the recursion takes them in order (v_readlane).  Off the decode path and slow by
+// nature (a few ms per frame of input), hence only when asked for: dabx_enable_level.
+template <int FMT>
+__global__ void k_level(const void *in, int64_t n, int first, int stride, float catt, float crel, State *st)
+{
+    const int lane = threadIdx.x;                         // 64 threads
+    float level = st->level;
+    for (int64_t base = first; base < n; base += (int64_t)64 * stride) {
+        const int64_t k = base + (int64_t)lane * stride;
+        float a = 0.0f;
+        if (k < n) {
+            const float2 v = in_sample<FMT>(in, k);
+            const float q2 = v.y * v.y;
+            a = v.x * v.x;
+            a = a + q2;
+        }
+        const int64_t left = (n - base + stride - 1) / stride;
+        const int cnt = left < 64 ? (int)left : 64;
+        for (int i = 0; i < cnt; ++i) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), i));
+            const float c = x > level ? catt : crel;
+            float p = c * x;
+            const float b = c * level;
+            p = p + level;
+            level = p - b;
+        }
+    }
+    if (lane == 0) st->level = level;
 }
 
 // ---- Transposed Farrow, one launch, for input rates up to 4096 kHz (R = 2048 kHz / rate >= 0.5).

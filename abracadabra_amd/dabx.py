@@ -23,7 +23,7 @@ DABX_SYMBOLS = [
     "dabx_push_resampled", "dabx_push_resampled_from", "dabx_get_input_peak", "dabx_get_superframe_pos", "dabx_read_ring", "dabx_flush_copies",
     "dabx_set_write_pos", "dabx_process", "dabx_process_async", "dabx_wait", "dabx_frames_available",
     "dabx_get_fib", "dabx_get_msc", "dabx_get_sync", "dabx_get_state", "dabx_get_fic_soft", "dabx_get_msc_soft",
-    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum", "dabx_get_null_spectra", "dabx_get_requeue_total", "dabx_last_shader_clock",
+    "dabx_get_fib_counts", "dabx_fft2048", "dabx_viterbi", "dabx_last_timing", "dabx_enable_timing", "dabx_rawfile_probe", "dabx_enable_spectrum", "dabx_get_spectrum", "dabx_get_null_spectrum", "dabx_get_null_spectra", "dabx_get_requeue_total", "dabx_last_shader_clock", "dabx_enable_level", "dabx_get_level",
 ]
 
 
@@ -212,6 +212,16 @@ class Context:
         if n < 0:
             _chk(int(n))
         return int(n)
+
+    def enable_level(self, stream, on=True):
+        self.L.dabx_enable_level.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _chk(self.L.dabx_enable_level(self.h, stream, 1 if on else 0))
+
+    def level(self, stream):
+        v = C.c_float()
+        self.L.dabx_get_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _chk(self.L.dabx_get_level(self.h, stream, C.byref(v)))
+        return v.value
 
     def flush_copies(self):
         self.L.dabx_flush_copies.argtypes = [C.c_void_p]

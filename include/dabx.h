@@ -125,7 +125,7 @@ DABX_API int dabx_push_all(dabx_ctx *ctx, const void *src, size_t src_stride_byt
  *   Farrow resampler.  src: host memory, n complex samples, interleaved I,Q as int16 (DABX_FMT_S16) or float
  *   (DABX_FMT_F32); every output sample is multiplied by `gain` and rounded to int16 (1.0 for int16 input; e.g.
  *   8192 for floats in +-1).  Filter state is kept per stream from call to call.  Returns the number of samples
- *   appended to the ring, or a negative error code.  The reference's signal-level output is not produced. */
+ *   appended to the ring, or a negative error code.  (The reference's signal-level output: dabx_enable_level.) */
 #define DABX_FMT_F32 2
 DABX_API int64_t dabx_push_resampled(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain);
 /* The same with the source kinds of dabx_push.  DABX_SRC_PINNED: the staging copy and the converter kernels are queued on the
@@ -134,6 +134,13 @@ DABX_API int64_t dabx_push_resampled(dabx_ctx *ctx, int stream, const void *src,
  * This is how the legacy adapter hands the float samples of the reference's input callback (dabsdr.h:387) to the GPU
  * without touching them on the host: in_rate_hz = 2048000, src_fmt = DABX_FMT_F32, gain = a power of two. */
 DABX_API int64_t dabx_push_resampled_from(dabx_ctx *ctx, int stream, const void *src, int64_t n, int src_fmt, double in_rate_hz, float gain, int src_kind);
+/* The converters' signal-level output, what the reference's SDR inputs steer their gain with (src/input/inputdevicesrc.h:60-75
+ * signalLevel(); the detector: inputdevicesrc.cpp:167-173, :282-292, :330-341 — fast attack 50 us, slow release 50 ms on |x|^2 of the
+ * input samples).  A serial binary32 recursion, run by one wave per push on the GPU (a few ms per frame of input, on the stream of
+ * the push): off by default, enabled per stream; enabling or disabling starts from level 0.  dabx_get_level waits for the pushes
+ * queued so far.  Bit-exact against the restatement in oracle/dab_src.c. */
+DABX_API int dabx_enable_level(dabx_ctx *ctx, int stream, int on);
+DABX_API int dabx_get_level(dabx_ctx *ctx, int stream, float *level);
 /* Largest |I| or |Q| (int16 units, after the gain) the converters wrote into the stream's ring between the submission of the
  * step before the last one and the submission of the last one; valid after dabx_wait.  (Input level for a caller's gain control.) */
 DABX_API int dabx_get_input_peak(dabx_ctx *ctx, int stream, int32_t *peak);

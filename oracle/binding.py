@@ -327,6 +327,9 @@ class Resampler:
         x = np.ascontiguousarray(iq_f32, dtype=np.float32)
         n = x.size // 2
         if self.kind == "copy":
+            self.L.osrc_passthrough_level.restype = C.c_float
+            self.L.osrc_passthrough_level.argtypes = [C.c_float, C.c_void_p, C.c_int]
+            self.copy_level = self.L.osrc_passthrough_level(getattr(self, "copy_level", 0.0), x.ctypes.data, n)
             return x.copy()
         out = np.zeros(2 * (n + 8), dtype=np.float32)
         if self.kind == "ds2":
@@ -336,6 +339,8 @@ class Resampler:
         return out[:2 * m].copy()
 
     def level(self):
+        if self.kind == "copy":
+            return float(getattr(self, "copy_level", 0.0))
         return float(self.L.osrc_ds2_level(self.state.ctypes.data) if self.kind == "ds2" else self.L.osrc_farrow_level(self.state.ctypes.data))
 
 

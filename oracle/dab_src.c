@@ -177,3 +177,21 @@ int osrc_farrow_process(osrc_farrow_t *s, const float *in, int n_cplx, float *ou
 float osrc_farrow_level(const osrc_farrow_t *s) { return s->level; }
 int osrc_sizeof_ds2(void) { return (int)sizeof(osrc_ds2_t); }
 int osrc_sizeof_farrow(void) { return (int)sizeof(osrc_farrow_t); }
+
+/* ------------------------------------------------------------------ pass-through (2048 kHz in): inputdevicesrc.cpp:314-345
+ * copies the samples and runs the level detector on every one of them (:330-341), constants of :316-317 */
+float osrc_passthrough_level(float level, const float *in, int n_cplx)
+{
+    const float catt = (float)(1 - exp(-1 / (LEVEL_ATTACK * 2048e3))), crel = (float)(1 - exp(-1 / (LEVEL_RELEASE * 2048e3)));
+    for (int n = 0; n < n_cplx; n++) {
+        float abs2 = in[2 * n] * in[2 * n];
+        const float q2 = in[2 * n + 1] * in[2 * n + 1];
+        abs2 = abs2 + q2;
+        const float c = abs2 > level ? catt : crel;
+        float a = c * abs2;
+        const float b = c * level;
+        a = a + level;
+        level = a - b;
+    }
+    return level;
+}

@@ -216,3 +216,32 @@ def test_gpu_resampler_asynchronous_pushes_from_pinned_memory(gpu_ctx_factory, r
     got = ctx.read_ring(0, 0, total)
     assert np.array_equal(got, np.concatenate(want)) and total > 100000
     ctx.free_pinned(pinned)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,dtype", [(4096e3, np.int16), (2400e3, np.float32), (6000e3, np.int16), (2048e3, np.float32)])
+def test_gpu_signal_level_equals_the_restatement(gpu_ctx_factory, rate, dtype):
+    """dabx_enable_level: the reference's level detector (fast attack, slow release on |x|^2 of the input samples; a serial binary32
+    recursion) run by one wave per push, bit-exact against oracle/dab_src.c over chunked pushes — a burst, silence, a weaker burst"""
+    rng = np.random.default_rng(5)
+    n = 60000
+    env = np.concatenate([np.full(n // 3, 9000.0), np.zeros(n // 3), np.full(n - 2 * (n // 3), 1500.0)])
+    x = (rng.normal(0, 1, 2 * n) * np.repeat(env, 2)).astype(np.float32)
+    gain = 1.0
+    if dtype == np.int16:
+        x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    else:
+        x, gain = x / np.float32(32768.0), 8192.0
+    ctx = gpu_ctx_factory(n_streams=2, fmt=1, ring_frames=4, max_frames=1)
+    ctx.enable_level(1, True)
+    orc = ob.Resampler(rate)
+    sizes = [2, 40, 1000, 30002] if rate == 4096e3 else [1, 3, 999, 30001]
+    seen = []
+    for a, b in _chunks(n, sizes):
+        part = x[2 * a:2 * b]
+        ctx.push_resampled(1, part, rate, gain)
+        orc.process(part.astype(np.float32))
+        seen.append((ctx.level(1), orc.level()))
+    assert all(g == o for g, o in seen), [s for s in seen if s[0] != s[1]][:3]
+    assert seen[-1][1] > 0 and max(o for _, o in seen) > 1.1 * seen[-1][1]      # it rose with the burst and has been falling since
+    assert ctx.level(0) == 0.0                                    # the other stream never asked
