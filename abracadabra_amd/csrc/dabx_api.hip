@@ -203,11 +203,11 @@ int build_work(dabx_ctx *c, int n_frames)
     std::vector<DevWork> all;
     for (int s = 0; s < c->cfg.n_streams; ++s)
         for (int f = 0; f < n_frames; ++f) {
-            for (int cw = 0; cw < 4; ++cw) all.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cw), -1, 0u, 774u});
+            for (int cw = 0; cw < 4; ++cw) all.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cw), -1, 774u});
             const auto &sh = c->streams[s];
             for (int cif = 0; cif < 4; ++cif)
                 for (size_t k = 0; k < sh.prof.size(); ++k)
-                    all.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cif), static_cast<int8_t>(k), 0u,
+                    all.push_back({s, static_cast<int16_t>(f), static_cast<int8_t>(cif), static_cast<int8_t>(k),
                                    static_cast<uint32_t>(sh.prof[k].steps())});
         }
     std::stable_sort(all.begin(), all.end(), [](const DevWork &a, const DevWork &b) { return a.nsteps > b.nsteps; });

@@ -41,7 +41,6 @@ struct DevWork {        // one Viterbi codeword = one wave
     int16_t frame;
     int8_t c;           // FIC codeword 0..3 or CIF 0..3
     int8_t sub;         // -1 = FIC
-    uint32_t scratch;   // (unused since round 3: scratch belongs to the waves of k_viterbi_requeue, not to codewords)
     uint32_t nsteps;
 };
 
