@@ -1040,7 +1040,7 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     const auto info = dabx::step_info(p);
     const int nsteps = p.steps();
     const size_t words = static_cast<size_t>((nsteps / 24 + 1) * 64);
-    if (nsteps % 48 != 6) return DABX_E_PROFILE;             // every DAB codeword: 48 k + 6 trellis steps
+    if (nsteps % 192 != 6) return DABX_E_PROFILE;            // every DAB codeword: 192 k + 6 trellis steps (24 ms x 8 kbit/s units; the FIC's 768)
     // the soft-bit contract of the decoder (twice the sum of two soft bits must fit a byte): refuse what breaks it
     for (size_t i = 0, n = static_cast<size_t>(n_cw) * p.n_coded; i < n; ++i)
         if (soft[i] > 31 || soft[i] < -31) return DABX_E_ARG;

@@ -831,17 +831,26 @@ __device__ __forceinline__ uint32_t soft_tab_entry(const VitSrc &src, uint32_t k
 // the buffers carry slack), shifted left by one inside their bytes, and the punctured ones are masked off.
 // (d16 byte loads that would drop the bytes into the halves of two registers were tried: on a GPU with SRAM ECC — this one — a d16
 // load clears the other half of its destination, so the bytes still have to be collected by instructions.)
-__device__ __forceinline__ int gather_step(const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
+struct Gather { uint32_t b0, b1, b2, b3, m; };       // m: the step's byte mask (the depuncturing word itself is dead once the loads are out)
+// issue: the four byte loads of the step described by w; they stay in flight until gather_finish
+__device__ __forceinline__ void gather_issue(Gather &g, const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
 {
     const uint32_t i0 = w >> 5;
     const uint32_t *t = tab + (i0 & 15u);
     const uint32_t q = (i0 >> 4) << sh;
     const uint8_t *base = reinterpret_cast<const uint8_t *>(src.base);
-    const uint32_t b0 = base[t[0] + q], b1 = base[t[1] + q], b2 = base[t[2] + q], b3 = base[t[3] + q];
-    const uint32_t W = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    g.b0 = base[t[0] + q]; g.b1 = base[t[1] + q]; g.b2 = base[t[2] + q]; g.b3 = base[t[3] + q];
     // every byte holds a value of -31..31: shifted left by one inside its byte it is twice that value; 0xFE per kept byte
     // clears the neighbour's sign bit that came in from below, 0 per punctured byte clears the byte
-    return (int)((W << 1) & (0xFEFEFEFEu >> (w & 31u)));
+    g.m = 0xFEFEFEFEu >> (w & 31u);
+}
+// finish, a loop iteration later: the A row.  The empty asm pins the place: left alone, the compiler collects the bytes right behind
+// the loads (the round's branch made that the natural spot) and the wave waits out their whole latency there.
+__device__ __forceinline__ int gather_finish(Gather &g)
+{
+    asm volatile("" : "+v"(g.b0), "+v"(g.b1), "+v"(g.b2), "+v"(g.b3));
+    const uint32_t W = g.b0 | (g.b1 << 8) | (g.b2 << 16) | (g.b3 << 24);
+    return (int)((W << 1) & g.m);
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
@@ -884,7 +893,9 @@ __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int la
 }
 #undef DABX_ACS_OPS
 
-constexpr int VIT_BLK = 48;          // trellis steps per soft-bit fetch block (lanes 0..47 fetch one step each) = two chunks
+constexpr int VIT_BLK = 48;          // trellis steps per loop iteration = two chunks of 24 (one decision word each)
+constexpr int VIT_XS = 192;          // staging ring of A rows: four iterations = THREE gather rounds of 64 steps, one step per lane
+constexpr int VIT_XS_WORDS = VIT_XS + 20;   // + the 19 entries of the gather's address table
 constexpr int VIT_RING = 16;         // decision words (24 steps each) a wave keeps in LDS: 4 KB
 constexpr int VIT_UNIT = 8;          // words decoded (or, without a merge, spilled) at a time: 192 steps = 6 output words
 
@@ -973,8 +984,8 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging buffer in LDS: the A rows of a block's 48 steps at dword 0 (64 written), the 19
-//           dwords of the address table at 64
+//   xs:     the wave's soft-value staging ring in LDS: the A rows of 192 steps (row of step t at dword t mod 192), the 19
+//           dwords of the address table behind them
 //   SPILL:  false = the first pass (k_viterbi): a codeword whose survivors do not merge gives up (returns false, dec is not
 //           touched) and is decoded again by k_viterbi_requeue, which has a block of scratch per wave (SPILL = true)
 template <bool SPILL>
@@ -1002,35 +1013,41 @@ __device__ bool viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const int nblk = nsteps / VIT_BLK;                           // full blocks of two chunks (even); the tail follows
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
     int w_dec = 0, w_ring = 0;                                   // first word not yet decoded / first word still in the ring
-    // Soft-bit pipeline, three blocks of 48 steps deep: the depuncturing words of block b+2 and
-    // the soft bytes of block b+1 are in flight while block b runs, so each of the two
-    // dependent loads has a whole block of ACS work to hide behind.
-    // byte offset of the lane's next depuncturing word: step lane, then 48 further per block; lanes 48..63 fetch nothing — they
-    // read one of the zero words behind the table and stay there (the tables carry kStepInfoPad of them: no clamping)
-    uint32_t toff = 4u * (uint32_t)(lane < VIT_BLK ? lane : nsteps + lane);
-    const uint32_t tinc = lane < VIT_BLK ? 4u * VIT_BLK : 0u;
+    // Soft-bit pipeline.  All 64 lanes gather: round R fetches the steps 64 R .. 64 R + 63 (one per lane) into the staging ring of 192
+    // A rows, three rounds per four loop iterations of 48 steps (round R of a super-block of 192 steps at its iteration R; none at the
+    // fourth).  The depuncturing words of the round after next and the soft bytes of the next round are in flight while an iteration
+    // runs, so each of the two dependent loads has at least an iteration of ACS work to hide behind.  (Until round 3: blocks of 48
+    // steps gathered by 48 lanes, a quarter of the gather's instructions spent on idle lanes.)  Every DAB codeword is 192 k + 6 steps.
+    // Byte offset of the lane's next depuncturing word: no clamping — the tables carry kStepInfoPad zero words behind their end.
+    uint32_t toff = 4u * (uint32_t)lane;
+    const uint32_t tinc = 4u * 64u;
     // A row of this lane: row r = the step of group r of a 24-step chunk (LDS byte address: the low 32 bits of a shared
     // pointer); the four addresses of a read (rows 0..3: six dwords apart) fall into four different LDS banks
     const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);
-    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + 64;
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + VIT_XS;
     const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // LDS byte address of the wave's decision ring
     const int sh = src.slot_mask < 0 ? 4 : 0;
-    if (lane < 19) xs[64 + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
+    if (lane < 19) xs[VIT_XS + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
     const char *infob = reinterpret_cast<const char *>(info);
-    int xa = gather_step(src, tab, sh, *reinterpret_cast<const uint32_t *>(infob + toff));
+    Gather ga;
+    gather_issue(ga, src, tab, sh, *reinterpret_cast<const uint32_t *>(infob + toff));
     toff += tinc;
     uint32_t wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
     toff += tinc;                                                // (the word this lane loads next)
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
-        xs[lane] = xa;                                           // lanes 48..63 write padding.  One buffer is enough: a wave's LDS
-                                                                 // operations execute in order, the previous block's reads are done
+        const int it = blk & 3;                                  // iteration inside the super-block of 192 steps (wave-uniform)
+        if (it != 3) {
+            // round `it`: rows 64 it .. 64 it + 63 of the ring.  They were last read two or more iterations ago, and a wave's LDS
+            // operations execute in order.  Iteration `it` reads rows 48 it .. 48 it + 47: all written by now.
+            xs[64 * it + lane] = gather_finish(ga);
 #ifndef DABX_PROBE_NOGATHER
-        xa = gather_step(src, tab, sh, wnext);
-        wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
-        toff += tinc;
+            gather_issue(ga, src, tab, sh, wnext);
+            wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
+            toff += tinc;
 #endif
-        const uint32_t va = va0;
+        }
+        const uint32_t va = va0 + 192u * (uint32_t)it;           // the iteration's first chunk: row 48 it
         uint32_t bits = 0;
         if (blk == nblk) {                                       // the six tail steps: no output, from state 0 (lane 0)
             acs6(pm, sk, va, lane_x32, bits);
@@ -1095,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_work) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][84];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][VIT_XS_WORDS];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
     if (!viterbi_item<false>(C, work[wi], nullptr, xs_all[wave], ring_all[wave]) && (threadIdx.x & 63) == 0)
         C.requeue[1 + atomicAdd(C.requeue, 1u)] = (uint32_t)wi;              // [0] = count, then the items
@@ -1126,7 +1143,7 @@ constexpr int VIT_RQ_BLOCKS = 64;
 __global__ __launch_bounds__(256) void k_viterbi_requeue(DevCtx C, const DevWork *__restrict__ work, uint32_t scratch_words_per_wave)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ __attribute__((aligned(16))) int xs_all[4][84];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][VIT_XS_WORDS];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];
     const uint32_t n = C.requeue[0];
     const uint32_t me = blockIdx.x * 4 + wave;
@@ -1142,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi = blockIdx.x * 4 + wave;
     if (wi >= n_cw) return;
-    __shared__ __attribute__((aligned(16))) int xs_all[4][84];
+    __shared__ __attribute__((aligned(16))) int xs_all[4][VIT_XS_WORDS];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
     VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
     (void)viterbi_wave<true>(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
