@@ -303,6 +303,36 @@ __device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const u
     derotate8(v, rot, step);                     // v[j] = cmul(x[j], rot_j), rot_j = cmul(rot_{j-1}, step)
 }
 
+// The same in two halves, for k_demod: the eight loads of the NEXT symbol's window travel while this symbol's FFT runs
+// (window_issue), and are turned into samples at the top of the next iteration (window_finish; the empty asm statement pins the
+// conversion there — left alone the compiler converts right behind the loads and the wave waits out their latency).
+template <int FMT>
+__device__ __forceinline__ void window_issue(uint32_t raw[8], const uint8_t *ring, int64_t widx, int t)
+{
+    const uint8_t *base = ring + widx * (FMT == 0 ? 2 : 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        raw[j] = FMT == 0 ? (uint32_t)reinterpret_cast<const uint16_t *>(base)[t + 256 * j] : reinterpret_cast<const uint32_t *>(base)[t + 256 * j];
+}
+template <int FMT>
+__device__ __forceinline__ void window_finish(cf v[8], uint32_t raw[8], const DevTables &T, uint32_t phase_off, int32_t inc, int t)
+{
+    const uint32_t dth = (uint32_t)(-(int64_t)inc);
+    const cf step = nco(T, dth * 256u);
+    const cf rot = nco(T, dth * (phase_off + (uint32_t)t));
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t u = raw[j];
+        if (FMT == 0) {
+            float a, b;
+            asm("v_cvt_f32_ubyte0 %0, %2\n\tv_cvt_f32_ubyte1 %1, %2" : "=&v"(a), "=v"(b) : "v"(u));
+            v[j] = (cf){a, b} + (cf){-128.0f, -128.0f};
+        } else v[j] = {(float)(int16_t)(u & 0xffff), (float)(int16_t)(u >> 16)};
+    }
+    derotate8(v, rot, step);
+}
+
 // integer CORDIC, angle of (x + j y) in 2^-32 turns
 __device__ int32_t cordic(int64_t y, int64_t x, const int32_t *tab)
 {
@@ -699,10 +729,13 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     const int l_last = l_first + DEMOD_GSYMS - 1;
     int64_t widx = wrap(rec.t_sym0 + (int64_t)l_ref * TS, C.ring_len);
     cf prev[8], v[8];
+    uint32_t raw[8];
+    window_issue<FMT>(raw, ring, widx, t);
     for (int l = l_ref; l <= l_last; ++l) {
-        load_window<FMT>(v, T, ring, C.ring_len, widx, (uint32_t)(l * TS), rec.inc, t);
+        window_finish<FMT>(v, raw, T, (uint32_t)(l * TS), rec.inc, t);
         widx += TS;
         if (widx >= C.ring_len) widx -= C.ring_len;
+        if (l < l_last) window_issue<FMT>(raw, ring, widx, t);           // the next symbol's samples travel during this symbol's FFT
 #ifdef DABX_PROBE_DEMOD_NOBARRIER
         fft2048_core<false>(v, buf, t, twa, nullptr, twc, twl);
 #else
