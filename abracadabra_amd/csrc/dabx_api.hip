@@ -92,7 +92,6 @@ struct dabx_ctx {
     float2 *d_W = nullptr, *d_nhi = nullptr, *d_nlo = nullptr;
     int16_t *d_bop = nullptr, *d_nob = nullptr, *d_car = nullptr;
     int8_t *d_pq = nullptr, *d_pdq = nullptr;
-    int32_t *d_cordic = nullptr;
     float *d_spectrum = nullptr, *d_null_spectrum = nullptr;   // optional, dabx_enable_spectrum
     DevState *h_state = nullptr;            // pinned mirror
     // single-stream contexts (the legacy 24-function path: one ensemble, one frame per step) get their small per-step
@@ -138,7 +137,7 @@ struct dabx_ctx {
     DevCtx dev() const
     {
         DevCtx c = {};
-        c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car, d_cordic};
+        c.tab = {d_W, d_nhi, d_nlo, d_bop, d_nob, d_pq, d_pdq, d_car};
         c.state = d_state; c.sync = d_sync; c.ring = d_ring; c.fic_soft = d_fic; c.ti = d_ti;
         c.fib = d_fib; c.fib_ok = d_fib_ok; c.msc = d_msc; c.msc_valid = d_msc_valid;
         c.sub = d_sub; c.stepinfo = d_info; c.prbs = d_prbs; c.dec_scratch = d_scratch; c.requeue = d_requeue; c.spectrum = d_spectrum; c.null_spectrum = d_null_spectrum;
@@ -183,15 +182,10 @@ int upload_tables(dabx_ctx *c)
         cfo.push_back(static_cast<int16_t>(k));
         vdq[k & 2047] = static_cast<int8_t>((pq[k & 2047] - pq[(k - 1) & 2047]) & 3);
     }
-    // round(atan(2^-i) / (2 pi) * 2^32)
-    std::vector<int32_t> cordic = {536870912, 316933406, 167458907, 85004756, 42667331, 21354465, 10679838, 5340245,
-                                   2670163,   1335087,   667544,    333772,   166886,   83443,    41722,    20861,
-                                   10430,     5215,      2608,      1304,     652,      326,      163,      81,
-                                   41,        20,        10,        5};
     int rc;
     if ((rc = dev_upload(c->d_W, W)) || (rc = dev_upload(c->d_nhi, hi)) || (rc = dev_upload(c->d_nlo, lo)) ||
         (rc = dev_upload(c->d_bop, bop)) || (rc = dev_upload(c->d_nob, nob)) || (rc = dev_upload(c->d_car, cfo)) ||
-        (rc = dev_upload(c->d_pq, vq)) || (rc = dev_upload(c->d_pdq, vdq)) || (rc = dev_upload(c->d_cordic, cordic)))
+        (rc = dev_upload(c->d_pq, vq)) || (rc = dev_upload(c->d_pdq, vdq)))
         return rc;
     return dev_upload(c->d_prbs, dabx::prbs_words(dabx::kCifBits));
 }
@@ -349,7 +343,8 @@ int dabx_create(const dabx_config_t *cfg, dabx_ctx **out)
 {
     if (!cfg || !out || cfg->n_streams < 1 || cfg->max_frames < 1 || cfg->max_frames > 60 ||
         (cfg->fmt != DABX_FMT_U8 && cfg->fmt != DABX_FMT_S16) ||
-        cfg->ring_samples < static_cast<int64_t>(cfg->max_frames + 2) * dabx::kTF)
+        cfg->ring_samples < static_cast<int64_t>(cfg->max_frames + 2) * dabx::kTF ||
+        cfg->ring_samples > (1LL << 30))                    // the kernels index one stream's ring with 32 bits (5 000 s of signal)
         return DABX_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) {
@@ -417,7 +412,7 @@ void dabx_destroy(dabx_ctx *c)
     if (c->d_clock) (void)hipFree(c->d_clock);
     void *bufs[] = {c->d_ring, c->d_state, c->d_sync, c->d_fic, c->d_ti, c->d_fib, c->d_fib_ok, c->d_msc, c->d_msc_valid,
                     c->d_sub, c->d_info, c->d_prbs, c->d_scratch, c->d_requeue, c->d_work, c->d_sf_subs, c->d_sf_state, c->d_sf_recs, c->d_sf_data, c->d_gf, c->d_spectrum, c->d_null_spectrum, c->d_W, c->d_nhi, c->d_nlo, c->d_bop,
-                    c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_cordic, c->d_rs_state, c->d_rs_in, c->d_rs_mu, c->d_rs_seg, c->d_rs_A, c->d_rs_x};
+                    c->d_nob, c->d_car, c->d_pq, c->d_pdq, c->d_rs_state, c->d_rs_in, c->d_rs_mu, c->d_rs_seg, c->d_rs_A, c->d_rs_x};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);

@@ -87,7 +87,6 @@ struct DevTables {
     const int8_t *prs_q;        // [2048] PRS quadrant (-1 unused)
     const int8_t *prs_dq;       // [2048] PRS quadrant difference k vs k-1
     const int16_t *cfo_car;     // [1534] carriers usable for the differential CFO search
-    const int32_t *cordic;      // [28]
 };
 
 struct DevCtx {

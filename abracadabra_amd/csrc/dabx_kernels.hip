@@ -259,6 +259,20 @@ __device__ __forceinline__ void sample(const uint8_t *ring, int64_t idx, int &i,
     else { uint32_t u = reinterpret_cast<const uint32_t *>(ring)[idx]; i = (int16_t)(u & 0xffff); q = (int16_t)(u >> 16); }
 }
 
+// the same in two halves, so that a batch of loads can be in flight with one register per sample
+template <int FMT>
+__device__ __forceinline__ uint32_t sample_raw(const uint8_t *ring, uint32_t idx)
+{
+    if (FMT == 0) return reinterpret_cast<const uint16_t *>(ring)[idx];
+    return reinterpret_cast<const uint32_t *>(ring)[idx];
+}
+template <int FMT>
+__device__ __forceinline__ void sample_unpack(uint32_t u, int &i, int &q)
+{
+    if (FMT == 0) { i = (int)(u & 0xff) - 128; q = (int)(u >> 8) - 128; }
+    else { i = (int16_t)(u & 0xffff); q = (int16_t)(u >> 16); }
+}
+
 __device__ __forceinline__ int64_t wrap(int64_t n, int64_t len)
 {
     int64_t w = n % len;
@@ -285,25 +299,7 @@ __device__ __forceinline__ cf sample_f(const uint8_t *ring, uint32_t idx)
 // by -inc with phase zero `phase_off` samples before the window.  The head of the ring is mirrored behind its end
 // (DABX_RING_MIRROR samples, kept by the host side), so the window never wraps: the eight loads of a thread are a
 // scalar base + 2 t + an immediate — no per-sample address arithmetic.
-template <int FMT>
-__device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const uint8_t *ring, int64_t ring_len,
-                                            int64_t widx, uint32_t phase_off, int32_t inc, int t)
-{
-    const uint32_t dth = (uint32_t)(-(int64_t)inc);
-    const cf step = nco(T, dth * 256u);
-    cf rot = nco(T, dth * (phase_off + (uint32_t)t));
-    const uint8_t *base = ring + widx * (FMT == 0 ? 2 : 4);                      // uniform: scalar registers
-#pragma unroll
-#ifdef DABX_PROBE_NOLOAD
-    for (int j = 0; j < 8; ++j) v[j] = {(float)((t + 7 * j) & 31) - 16.0f, (float)((t * 3 + j) & 31) - 16.0f};   // timing probe: no memory
-    (void)base;
-#else
-    for (int j = 0; j < 8; ++j) v[j] = sample_f<FMT>(base, (uint32_t)(t + 256 * j));
-#endif
-    derotate8(v, rot, step);                     // v[j] = cmul(x[j], rot_j), rot_j = cmul(rot_{j-1}, step)
-}
-
-// The same in two halves, for k_demod: the eight loads of the NEXT symbol's window travel while this symbol's FFT runs
+// In two halves for k_demod: the eight loads of the NEXT symbol's window travel while this symbol's FFT runs
 // (window_issue), and are turned into samples at the top of the next iteration (window_finish; the empty asm statement pins the
 // conversion there — left alone the compiler converts right behind the loads and the wave waits out their latency).
 template <int FMT>
@@ -333,9 +329,39 @@ __device__ __forceinline__ void window_finish(cf v[8], uint32_t raw[8], const De
     derotate8(v, rot, step);
 }
 
-// integer CORDIC, angle of (x + j y) in 2^-32 turns
-__device__ int32_t cordic(int64_t y, int64_t x, const int32_t *tab)
+// both halves back to back (k_sync, k_null_search): the phase table reads of window_finish overlap the sample loads
+template <int FMT>
+__device__ __forceinline__ void load_window(cf v[8], const DevTables &T, const uint8_t *ring, int64_t ring_len,
+                                            int64_t widx, uint32_t phase_off, int32_t inc, int t)
 {
+#ifdef DABX_PROBE_NOLOAD
+    const uint32_t dth = (uint32_t)(-(int64_t)inc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = {(float)((t + 7 * j) & 31) - 16.0f, (float)((t * 3 + j) & 31) - 16.0f};   // timing probe: no memory
+    derotate8(v, nco(T, dth * (phase_off + (uint32_t)t)), nco(T, dth * 256u));
+#else
+    uint32_t raw[8];
+    window_issue<FMT>(raw, ring, widx, t);
+    window_finish<FMT>(v, raw, T, phase_off, inc, t);
+#endif
+}
+
+// the eight output bins of thread t (bin_of_pos[8 t .. 8 t + 7]) in one 16-byte load
+__device__ __forceinline__ void load_bins(const DevTables &T, int t, int b[8])
+{
+    const uint4 w = *reinterpret_cast<const uint4 *>(T.bin_of_pos + 8 * t);
+    b[0] = w.x & 0xffff; b[1] = w.x >> 16; b[2] = w.y & 0xffff; b[3] = w.y >> 16;
+    b[4] = w.z & 0xffff; b[5] = w.z >> 16; b[6] = w.w & 0xffff; b[7] = w.w >> 16;
+}
+
+// integer CORDIC, angle of (x + j y) in 2^-32 turns.  The table, round(atan(2^-i) / (2 pi) * 2^32), is spelled out so that the
+// unrolled loop carries literals: read from memory it was 28 dependent round trips on the one lane every other phase waits for.
+__device__ __forceinline__ int32_t cordic(int64_t y, int64_t x)
+{
+    constexpr uint32_t tab[28] = {536870912, 316933406, 167458907, 85004756, 42667331, 21354465, 10679838, 5340245,
+                                  2670163,   1335087,   667544,    333772,   166886,   83443,    41722,    20861,
+                                  10430,     5215,      2608,      1304,     652,      326,      163,      81,
+                                  41,        20,        10,        5};
     if (x == 0 && y == 0) return 0;
     uint64_t ax = (uint64_t)(x < 0 ? -x : x), ay = (uint64_t)(y < 0 ? -y : y), m = ax > ay ? ax : ay;
     int sh = 0;
@@ -344,10 +370,11 @@ __device__ int32_t cordic(int64_t y, int64_t x, const int32_t *tab)
     else while ((m << 1) < (1ULL << 29)) { m <<= 1; x *= 2; y *= 2; }
     uint32_t ang = 0;
     if (x < 0) { x = -x; y = -y; ang = 0x80000000u; }
+#pragma unroll
     for (int i = 0; i < 28; i++) {
         int64_t xs = x >> i, ys = y >> i;
-        if (y > 0) { x += ys; y -= xs; ang += (uint32_t)tab[i]; }
-        else       { x -= ys; y += xs; ang -= (uint32_t)tab[i]; }
+        if (y > 0) { x += ys; y -= xs; ang += tab[i]; }
+        else       { x -= ys; y += xs; ang -= tab[i]; }
     }
     return (int32_t)ang;
 }
@@ -478,25 +505,45 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     int64_t cre = 0, cim = 0, en = 0, es = 0;
     {
         const int64_t g0 = wrap(pos_f + TNULL, C.ring_len);
-        for (int k = t; k < 4 * 408; k += 256) {
-            int sy = k / 408, n = 48 + k % 408;
-            int64_t a = g0 + (int64_t)sy * TS + n;
-            if (a >= C.ring_len) a -= C.ring_len;
-            int64_t b = a + TU;
-            if (b >= C.ring_len) b -= C.ring_len;
-            int i1, q1, i2, q2;
-            sample<FMT>(ring, a, i1, q1); sample<FMT>(ring, b, i2, q2);
-            cre += (int64_t)i1 * i2 + (int64_t)q1 * q2;
-            cim += (int64_t)q1 * i2 - (int64_t)i1 * q2;
+        // both loops are unrolled by hand with every load issued before the first use: left as loops the compiler waits for
+        // each pair of samples in turn, fifteen exposed round trips to memory in a kernel that is latency from end to end
+        // (32-bit ring offsets here: a ring is far below 2^31 samples, dabx_create checks it, and a 64-bit address per load
+        // in flight does not fit the 128 registers)
+        const uint32_t L = (uint32_t)C.ring_len, p0 = (uint32_t)wrap(pos_f, C.ring_len), g32 = (uint32_t)g0;
+        uint32_t ga[7], gb[7], ea[8], eb[8];
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            int k = t + 256 * it;
+            if (k >= 4 * 408) k = 4 * 408 - 1;              // the tail lanes of the last round re-read one sample; masked below
+            uint32_t sy = (uint32_t)k / 408u, n = 48u + (uint32_t)k % 408u;
+            uint32_t a = g32 + sy * TS + n;
+            if (a >= L) a -= L;
+            uint32_t b = a + TU;
+            if (b >= L) b -= L;
+            ga[it] = sample_raw<FMT>(ring, a); gb[it] = sample_raw<FMT>(ring, b);
         }
         // sample energy inside the null symbol and inside the PRS (SNR estimate for the host)
-        const int64_t p0 = wrap(pos_f, C.ring_len);
-        for (int n = t; n < TU; n += 256) {
-            int64_t a = p0 + 128 + n, b = p0 + TNULL + TG + n;
-            if (a >= C.ring_len) a -= C.ring_len;
-            if (b >= C.ring_len) b -= C.ring_len;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            uint32_t n = t + 256 * it;
+            uint32_t a = p0 + 128 + n, b = p0 + TNULL + TG + n;
+            if (a >= L) a -= L;
+            if (b >= L) b -= L;
+            ea[it] = sample_raw<FMT>(ring, a); eb[it] = sample_raw<FMT>(ring, b);
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            if (t + 256 * it < 4 * 408) {
+                int i1, q1, i2, q2;
+                sample_unpack<FMT>(ga[it], i1, q1); sample_unpack<FMT>(gb[it], i2, q2);
+                cre += (int64_t)i1 * i2 + (int64_t)q1 * q2;
+                cim += (int64_t)q1 * i2 - (int64_t)i1 * q2;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
             int i1, q1, i2, q2;
-            sample<FMT>(ring, a, i1, q1); sample<FMT>(ring, b, i2, q2);
+            sample_unpack<FMT>(ea[it], i1, q1); sample_unpack<FMT>(eb[it], i2, q2);
             en += (int64_t)i1 * i1 + (int64_t)q1 * q1;
             es += (int64_t)i2 * i2 + (int64_t)q2 * q2;
         }
@@ -513,7 +560,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
         es = red64[3] + red64[7] + red64[11] + red64[15];
     }
     if (t == 0) {
-        int32_t A = cordic(cim, cre, T.cordic);
+        int32_t A = cordic(cim, cre);
         int32_t inc_meas = (int32_t)((-(int64_t)A) >> 11);
         int32_t inc = inc_meas;
         if (!wide) {
@@ -568,13 +615,15 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     }
     // 3. conj(X * conj(P)) in natural order, second FFT -> impulse response
     __syncthreads();
+    int bins[8], pq[8];
+    load_bins(T, t, bins);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pq[e] = T.prs_q[bins[e]];         // all eight in flight before the first is used
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        int b = T.bin_of_pos[8 * t + e];
-        int q = T.prs_q[b];
         cf r = {0.0f, 0.0f};
-        if (q >= 0) r = rotq(v[e], q);
-        nat[b] = make_float2(r.x, -r.y);
+        if (pq[e] >= 0) r = rotq(v[e], pq[e]);
+        nat[bins[e]] = make_float2(r.x, -r.y);
     }
     __syncthreads();
 #pragma unroll
@@ -583,11 +632,12 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
     fft2048_core(v, buf, t, twa, nullptr, nullptr, twl);
     float acc = 0.0f, peak = -1.0f;
     int pidx = 0;
+    load_bins(T, t, bins);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float a = v[e].x * v[e].x, b = v[e].y * v[e].y, m2 = a + b;
         acc = acc + m2;
-        int n = T.bin_of_pos[8 * t + e];
+        int n = bins[e];
         if (m2 > peak || (m2 == peak && n < pidx)) { peak = m2; pidx = n; }
     }
     float total = reduce256(acc, red, t);
@@ -607,7 +657,7 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
         int dmax = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int d = (pidx - T.bin_of_pos[8 * t + e]) & 2047;
+            const int d = (pidx - bins[e]) & 2047;
             const float a = v[e].x * v[e].x, b = v[e].y * v[e].y, m2 = a + b;
             if (d != 0 && d <= EARLY_SPAN && m2 >= thr && d > dmax) dmax = d;
         }

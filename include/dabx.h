@@ -52,7 +52,7 @@ enum { DABX_FMT_U8 = 0, DABX_FMT_S16 = 1 };
 typedef struct {
     int32_t n_streams;            /* independent ensembles decoded side by side           */
     int32_t fmt;                  /* DABX_FMT_*                                           */
-    int64_t ring_samples;         /* per-stream IQ ring capacity in complex samples       */
+    int64_t ring_samples;         /* per-stream IQ ring capacity in complex samples: (max_frames + 2) frames .. 2^30 */
     int32_t max_frames;           /* largest n_frames dabx_process will be called with    */
     int32_t device;               /* HIP device ordinal                                   */
 } dabx_config_t;
