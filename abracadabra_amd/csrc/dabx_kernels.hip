@@ -157,7 +157,7 @@ __device__ __forceinline__ void load_twiddles_lds(cf a[7], float2 *twl, const fl
 }
 
 // in: v[j] = x[t + 256 j]; out: v[e] = X[bin_of_pos(8 t + e)].  buf: FFT_LDS float2.
-// The caller must __syncthreads() before the next use of buf.
+// The caller must __syncthreads() before the next use of buf (and before it reads buf itself: the last exchange is wave-local).
 // twa/twb/twc: the thread's twiddles of the three radix-8 passes (registers), or, when twl is given,
 // passes B and C read theirs from the LDS table of load_twiddles_lds().
 template <bool SYNC = true>
@@ -192,13 +192,36 @@ __device__ __forceinline__ void fft2048_core(cf v[8], float2 *buf, int t, const 
         for (int c = 0; c < 7; ++c) { const float2 x = twl[7 * 32 + (t & 3) * 7 + c]; w[c] = {x.x, x.y}; }
         cmul7(v, w);
     }
+    // The last exchange stays inside a quad of lanes: row t >> 2 of the buffer is written and read by lanes 4 (t >> 2) .. + 3 only,
+    // which run in lockstep in one wave.  So it needs no workgroup barrier (the LDS serves a wave's operations in order), and it
+    // may lay the row out differently from the exchange before it: the 16-byte slots (two values) of a row are stored with slot
+    // bit 0 flipped in the lanes with bit 4 set.  Read as they lie, the four 16-byte reads of a thread cost two LDS cycles each:
+    // ds_read_b128 serves lanes {0-3, 12-15, 20-27} together (MI355X_MICROARCH.md, LDS), and rows 0 and 6, 3 and 5 start on the
+    // same 16-byte column.  With the flip every group covers the 16 columns once (64 of 212 conflict cycles per symbol gone).
+#ifdef DABX_PROBE_EXCH_NOFLIP
+    const int flip = 0;                                          // timing probe
+#else
+    const int flip = (t >> 4) & 1;
+#endif
+    {
+        const int b3 = (t >> 2) * 32 + 2 * (((t >> 1) & 1) ^ flip) + (t & 1);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) buf[pad(base + 4 * c)] = make_float2(v[c].x, v[c].y);
-    if (SYNC) __syncthreads();                                   // (SYNC = false: timing probe only)
-    {   // positions 8t .. 8t+7 are contiguous (never across a pad): four 16-byte reads, conflict-free per 8 lanes
+        for (int c = 0; c < 8; ++c) buf[pad(b3 + 4 * c)] = make_float2(v[c].x, v[c].y);
+    }
+#ifdef DABX_PROBE_EXCH_BARRIER
+    __syncthreads();                                             // timing probe
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+    {   // positions 8t .. 8t+7 are contiguous (never across a pad): four 16-byte reads; slot e lies at e ^ flip = e +- flip
         const float4 *p = reinterpret_cast<const float4 *>(buf + pad(8 * t));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { float4 x = p[e]; v[2 * e] = {x.x, x.y}; v[2 * e + 1] = {x.z, x.w}; }
+        const float4 *pe = p + flip, *po = p - flip;
+        { float4 x = pe[0]; v[0] = {x.x, x.y}; v[1] = {x.z, x.w}; }
+        { float4 x = po[1]; v[2] = {x.x, x.y}; v[3] = {x.z, x.w}; }
+        { float4 x = pe[2]; v[4] = {x.x, x.y}; v[5] = {x.z, x.w}; }
+        { float4 x = po[3]; v[6] = {x.x, x.y}; v[7] = {x.z, x.w}; }
     }
     r4(v[0], v[1], v[2], v[3]);
     r4(v[4], v[5], v[6], v[7]);
@@ -724,7 +747,7 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
     const DevTables &T = C.tab;
     __shared__ __attribute__((aligned(16))) float2 buf[FFT_LDS];
     __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) uint16_t soft[NCAR + 64];   // one (Re, Im) soft-bit pair per carrier + a dummy slot per lane
+    __shared__ __attribute__((aligned(16))) uint16_t soft[NCAR + 8];    // one (Re, Im) soft-bit pair per carrier + one dummy slot
     const uint8_t *ring = C.ring + (size_t)s * C.ring_bytes;
     int8_t *fic = C.fic_soft + ((size_t)s * C.max_frames + f) * FICBITS;
     int8_t *ti = C.ti + (size_t)s * C.ti_slots * CIFBITS;
@@ -741,15 +764,16 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 #endif
     // where the soft-bit pair of each FFT output position goes in the staging buffer: the frequency de-interleaver index n
     // itself for FIC symbols ([0]), its residue-major place (n & 15) * 96 + (n >> 4) for MSC symbols ([1]); the bins
-    // outside the 1536 carriers go to a dummy slot of the lane (no branch around the store), used[] masks them out of the sum
+    // outside the 1536 carriers all go to ONE dummy slot (no branch around the store; lanes storing to one dword do not conflict,
+    // a slot per lane did: 15 of the scatter's 135 conflict cycles per symbol), used[] masks them out of the sum
     __shared__ __attribute__((aligned(16))) uint16_t dst_l[2][TU];         // BYTE offsets into soft[] (2 x the index): one 16-byte read per symbol and thread
     uint32_t used = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int n = T.n_of_bin[T.bin_of_pos[8 * t + e]];
         used |= (n >= 0 ? 1u : 0u) << e;
-        dst_l[0][8 * t + e] = static_cast<uint16_t>(2 * (n < 0 ? NCAR + (t & 63) : n));
-        dst_l[1][8 * t + e] = static_cast<uint16_t>(2 * (n < 0 ? NCAR + (t & 63) : (n & 15) * (NCAR / 16) + (n >> 4)));
+        dst_l[0][8 * t + e] = static_cast<uint16_t>(2 * (n < 0 ? NCAR : n));
+        dst_l[1][8 * t + e] = static_cast<uint16_t>(2 * (n < 0 ? NCAR : (n & 15) * (NCAR / 16) + (n >> 4)));
     }
 
     // Sampling-clock offset: the windows keep their nominal spacing, so a recording whose clock is off by eps sees every
