@@ -48,12 +48,12 @@ def run(frames=3000, timeout=120, long_codewords=False):
         exe = build_tool(d)
         sig = os.path.join(d, "periodic.u8")
         make_signal(sig)
-        legs = [("fic_only", [], sig), ("one_service_48cu", [hex(SID)], sig)]
+        legs = [("fic_only", [], sig, "none (FIC only)"), ("one_service_48cu", [hex(SID)], sig, "one 48-CU DAB+ service (64 kbit/s, EEP 3-A)")]
         if long_codewords:
             big = os.path.join(d, "periodic_big.u8")
             make_signal(big, big=True)
-            legs.append(("one_service_416cu_mp2", [hex(SID)], big))
-        for name, extra, sig in legs:
+            legs.append(("one_service_416cu_mp2", [hex(SID)], big, "one 416-CU MPEG Layer II service (384 kbit/s, UEP 1)"))
+        for name, extra, sig, what in legs:
             p = subprocess.run([exe, sig, str(frames)] + extra, capture_output=True, text=True, timeout=timeout)
             line = (p.stdout.strip().splitlines() or ["{}"])[-1]
             try:
@@ -61,6 +61,7 @@ def run(frames=3000, timeout=120, long_codewords=False):
             except ValueError:
                 out[name] = {"error": "unparsable", "stdout": p.stdout[-300:], "stderr": p.stderr[-300:]}
             out[name]["rc"] = p.returncode
+            out[name]["service"] = what
     return out
 
 

@@ -105,7 +105,7 @@ int main(int argc, char **argv)
     printf("{\"frames\": %.1f, \"seconds\": %.4f, \"x_realtime\": %.1f, \"ms_per_frame\": %.4f, \"sync_level\": %d, \"periodic_ntf\": %ld, "
            "\"fib_errors\": %ld, \"access_units\": %ld, \"au_crc_ok\": %ld, \"au_crc_err\": %ld, \"au_concealed\": %ld, \"service\": \"%s\"}\n",
            done, dt, done * 0.096 / dt, dt / done * 1e3, level, n_periodic - p0, fib_err - e0, n_au - a0, crc_ok - c0, crc_err - x0,
-           au_concealed - k0, want_sid ? "one 48-CU DAB+ service" : "none (FIC only)");
+           au_concealed - k0, want_sid ? "the primary audio component of the given SId" : "none (FIC only)");
     dabsdrRequest_Exit(H); dabsdrDeinit(&H);
     return 0;
 }
