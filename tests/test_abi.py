@@ -46,6 +46,17 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert aa.load_library().dabsdrInit(C.byref(h)) != 0 and not h.value
 
 
+def test_create_rejects_configurations_the_kernels_cannot_index():
+    """Argument checks come before any device call, so they run without a GPU: the kernels index one stream's ring with 32 bits
+    (dabx.h: (max_frames + 2) frames <= ring_samples <= 2^30), a step holds at most 60 frames, the formats are u8 and s16."""
+    L = aa.load_library()
+    TF = 196608
+    for cfg in (dabx.Config(1, 0, (1 << 30) + 1, 4, 0), dabx.Config(1, 0, 5 * TF, 4, 0), dabx.Config(0, 0, 16 * TF, 4, 0),
+                dabx.Config(1, 2, 16 * TF, 4, 0), dabx.Config(1, 0, 80 * TF, 61, 0)):
+        h = C.c_void_p()
+        assert L.dabx_create(C.byref(cfg), C.byref(h)) == -1 and not h.value         # DABX_E_ARG
+
+
 def test_fig_database_reads_transmitted_fibs():
     sub = [[0, 0, 3, 64], [48, 1, 4, 32], [100, 2, 17, 0]]
     _, fib, _ = ob.tx_generate(seed=4, eid=0x10AB, n_frames=3, subch=sub, snr_db=100.0)
