@@ -104,6 +104,7 @@ struct dabx_ctx {
     std::vector<uint32_t> info_pool;        // depuncturing maps, FIC first
     std::vector<dabx::Profile> pool_prof;
     std::vector<int> pool_off;
+    std::vector<char> pool_linear;
     std::vector<DevSub> h_sub;
     bool work_dirty = true;
     int work_frames = 0, n_work = 0;
@@ -147,14 +148,17 @@ struct dabx_ctx {
         return c;
     }
 
-    int pool_lookup(const dabx::Profile &p)
+    // gather maps (dabx_spec.hpp: step_gather) of the profiles in use, each once; offset in words.  FIC codewords are read from
+    // linear rows, sub-channels from the residue-major rows of the time de-interleaver.
+    int pool_lookup(const dabx::Profile &p, bool linear = false)
     {
         for (size_t i = 0; i < pool_prof.size(); ++i)
-            if (pool_prof[i] == p) return pool_off[i];
+            if (pool_prof[i] == p && pool_linear[i] == linear) return pool_off[i];
         const int off = static_cast<int>(info_pool.size());
-        const auto info = dabx::step_info(p);
+        const auto info = dabx::step_gather(p, linear);
         info_pool.insert(info_pool.end(), info.begin(), info.end());
         pool_prof.push_back(p);
+        pool_linear.push_back(linear);
         pool_off.push_back(off);
         return off;
     }
@@ -396,7 +400,7 @@ static int create_body(dabx_ctx *c, const dabx_config_t *cfg)
     c->h_sub.assign(S * 64, DevSub{});
     int rc = upload_tables(c);
     if (rc) return rc;
-    c->pool_lookup(dabx::fic_profile());                 // offset 0
+    c->pool_lookup(dabx::fic_profile(), true);           // offset 0
     return dev_upload(c->d_info, c->info_pool);
 }
 
@@ -977,16 +981,20 @@ int dabx_get_msc_soft(dabx_ctx *c, int s, int8_t *msc)
 {
     GETTER_PROLOGUE
     if (!msc) return DABX_E_ARG;
-    // the CIFs of the last step sit in rows (cif_end - 4n + k) & (slots-1) of the ring
+    // k_demod files residue class q of CIF c in the row of the logical frame it belongs to, c - bitrev4(q) (dabx_dev.h); the CIFs of
+    // the last step are cif_end - 4n .. cif_end - 1.  Hand them out CIF by CIF in natural bit order.
     const int64_t cif_end = c->streams[s].st.cif;
-    std::vector<int8_t> rowbuf(DABX_CIF_SOFT_BITS);
     constexpr int seg = DABX_CIF_SOFT_BITS / 16;
+    std::vector<int8_t> ringbuf(static_cast<size_t>(c->ti_slots) * DABX_CIF_SOFT_BITS);
+    HIPCHK(hipMemcpy(ringbuf.data(), c->d_ti + static_cast<size_t>(s) * c->ti_slots * DABX_CIF_SOFT_BITS, ringbuf.size(), hipMemcpyDeviceToHost));
+    static const int delay[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
     for (size_t k = 0; k < n * 4; ++k) {
-        const size_t row = static_cast<size_t>((cif_end - static_cast<int64_t>(n * 4) + static_cast<int64_t>(k)) & (c->ti_slots - 1));
-        HIPCHK(hipMemcpy(rowbuf.data(), c->d_ti + (static_cast<size_t>(s) * c->ti_slots + row) * DABX_CIF_SOFT_BITS,
-                         DABX_CIF_SOFT_BITS, hipMemcpyDeviceToHost));
-        // rows are stored residue-major on the device (dabx_dev.h); hand them out in natural bit order
-        for (int b = 0; b < DABX_CIF_SOFT_BITS; ++b) msc[k * DABX_CIF_SOFT_BITS + b] = rowbuf[(b & 15) * seg + (b >> 4)];
+        const int64_t cif = cif_end - static_cast<int64_t>(n * 4) + static_cast<int64_t>(k);
+        for (int q = 0; q < 16; ++q) {
+            const size_t row = static_cast<size_t>((cif - delay[q]) & (c->ti_slots - 1));
+            const int8_t *src = ringbuf.data() + row * DABX_CIF_SOFT_BITS + static_cast<size_t>(q) * seg;
+            for (int m = 0; m < seg; ++m) msc[k * DABX_CIF_SOFT_BITS + static_cast<size_t>(16 * m + q)] = src[m];
+        }
     }
     return DABX_OK;
 }
@@ -1032,7 +1040,7 @@ int dabx_viterbi(dabx_ctx *c, int kind, int option, int level, int kbps, const i
     (void)hipSetDevice(c->cfg.device);              /* a host may drive several contexts (GPUs) from one thread */
     dabx::Profile p = dabx::fic_profile();
     if (kind != 0 && !dabx::any_profile(option, level, kbps, p)) return DABX_E_PROFILE;
-    const auto info = dabx::step_info(p);
+    const auto info = dabx::step_gather(p, true);
     const int nsteps = p.steps();
     const size_t words = static_cast<size_t>((nsteps / 24 + 1) * 64);
     if (nsteps % 192 != 6) return DABX_E_PROFILE;            // every DAB codeword: 192 k + 6 trellis steps (24 ms x 8 kbit/s units; the FIC's 768)

@@ -5,11 +5,13 @@
 //   ring      [S][ring_samples]            raw IQ, u8 pairs or s16 pairs (the reference's
 //                                           raw-file formats, src/input/rawfileinput.cpp:640-713)
 //   fic_soft  [S][F][9216]        int8      FIC soft bits, frequency de-interleaved
-//   ti        [S][ti_slots][55296] int8     MSC soft bits, one row per CIF: the time
-//                                           de-interleaver ring (>= 15 + 4 F rows).  Inside a
-//                                           row bit b sits at (b & 15) * 3456 + (b >> 4)
-//                                           (residue-major): a logical frame reads one residue
-//                                           class from each of 16 rows, so its reads are contiguous
+//   ti        [S][ti_slots][55296] int8     MSC soft bits, time DE-interleaved: one row per LOGICAL
+//                                           frame (>= 15 + 4 F rows).  Inside a row bit b sits at
+//                                           (b & 15) * 3456 + (b >> 4) (residue-major).  k_demod files
+//                                           residue class q of CIF c in row (c - bitrev4(q)) & (ti_slots-1),
+//                                           192 contiguous bytes per symbol and class, so a codeword's
+//                                           bits sit at offsets that depend on its profile only
+//                                           (dabx_spec.hpp: step_gather)
 //   fib       [S][F][12][32]                decoded FIBs;  fib_ok [S][F][12]
 //   msc       [S][F][4][msc_stride]         decoded sub-channel bytes;  msc_valid [S][F][4]
 //   sync      [S][F]                        per-frame synchronisation records
@@ -19,7 +21,7 @@
 
 struct DevState {
     int64_t pos;        // estimated start of the next frame's null symbol
-    int64_t cif;        // CIFs demodulated since lock (ring row = cif & (ti_slots-1))
+    int64_t cif;        // CIFs demodulated since lock (row of logical frame r = r & (ti_slots-1); frame cif - 15 is the newest complete one)
     int32_t inc;        // carrier offset, 2^-32 turn per sample
     int32_t locked;
     int32_t bad;        // consecutive frames without PRS
@@ -47,7 +49,7 @@ struct DevWork {        // one Viterbi codeword = one wave
 struct DevSub {
     int32_t start_bit;  // first soft bit of the sub-channel inside a CIF row
     int32_t nsteps, n_in;
-    int32_t info_off;   // offset into stepinfo
+    int32_t info_off;   // offset of the profile's gather map in stepinfo (words)
     int32_t out_off;    // byte offset inside the CIF's output record
 };
 
@@ -98,7 +100,7 @@ struct DevCtx {
     int8_t *ti;
     uint8_t *fib, *fib_ok, *msc, *msc_valid;
     const DevSub *sub;          // [S][64]
-    const uint32_t *stepinfo;   // pooled depuncturing maps
+    const uint32_t *stepinfo;   // pooled gather maps (step_gather: five arrays of nsteps + 256 words each)
     const uint32_t *prbs;       // energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
     uint32_t *dec_scratch;      // k_viterbi_requeue: per wave the decision words of one codeword, 64 words per 24 trellis steps
     uint32_t *requeue;          // [0] number of codewords k_viterbi gave up on (survivors did not merge), [1..cap] their work

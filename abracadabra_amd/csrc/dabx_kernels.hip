@@ -857,9 +857,13 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
                     imoff = NCAR;
                 } else {
                     // residue-major row: bit b of the CIF lives at (b & 15) * TI_SEG + (b >> 4): 16 segments of 192 bytes
-                    // per symbol, each Re (96 bytes) then Im (96 bytes); the staging buffer is in that order
-                    int8_t *row = ti + (size_t)((cif0 + (l - 4) / 18) & (C.ti_slots - 1)) * CIFBITS;
+                    // per symbol, each Re (96 bytes) then Im (96 bytes); the staging buffer is in that order.  The time de-interleaver
+                    // is applied HERE: residue class q of CIF c belongs to logical frame c - bitrev4(q) (EN 300 401 §12) and is filed
+                    // in that frame's row, so the decoder finds a whole logical frame in ONE row and the places of a codeword's bits no
+                    // longer depend on the frame (k_viterbi reads them from a table made once per profile).
                     const int res = t / 6, part = t % 6;
+                    const int64_t frame = cif0 + (l - 4) / 18 - (int64_t)(__builtin_bitreverse32((uint32_t)res) >> 28);
+                    int8_t *row = ti + (size_t)(frame & (C.ti_slots - 1)) * CIFBITS;
                     dst = row + res * TI_SEG + ((l - 4) % 18) * (SYMBITS / 16) + 16 * part;
                     imoff = NCAR / 16;
                 }
@@ -905,59 +909,60 @@ __device__ __forceinline__ int conv_out0(int state)
     return o;
 }
 
-struct VitSrc {
-    const int8_t *base;       // soft bits of the codeword's first coded bit (row 0)
-    int64_t r;                // logical frame index (time de-interleaved) or 0
-    int slot_mask;            // ti_slots-1, or -1 for linear codewords
-};
-
-// MSC rows are stored residue-major (TI_SEG = 55296/16 bytes per residue class of the bit
-// index): logical frame r takes exactly one residue class from each of 16 rows, so this
-// layout makes every (row, residue) read contiguous instead of one byte per 16.
-//
-// Byte offset (from src.base) of coded bit i of the codeword = tab[i & 15] + ((i >> 4) << sh): the 16 residue
-// classes of a codeword start at 16 fixed places.  Time de-interleaved: class k lives in row (r + bitrev4(k)) of the
-// ring, at k * TI_SEG inside it (sub-channels start on 64-bit boundaries, so base already points at start_bit >> 4),
-// consecutive members one byte apart (sh = 0).  Linear (FIC, stage tests): tab[k] = k, members 16 bytes apart (sh = 4).
-// Entries 16..18 continue the table for bits i+1..i+3 of a step that starts in class 13..15: tab[k - 16] + (1 << sh).
-// The wave keeps the table in LDS: the four addresses of a step cost one and / shift-add, four reads with immediate
-// offsets and four adds.
-__device__ __forceinline__ uint32_t soft_tab_entry(const VitSrc &src, uint32_t k)
-{
-    const uint32_t wrap = k >> 4;
-    k &= 15u;
-    if (src.slot_mask < 0) return k + (wrap << 4);
-    const uint32_t d = __builtin_bitreverse32(k) >> 28;            // delay of residue class k: bit-reversed k
-    // the offset stays below 2^32 (at most 64 rows of 55296 bytes): 24-bit multiplies
-    return __umul24(((uint32_t)src.r + d) & (uint32_t)src.slot_mask, (uint32_t)CIFBITS) + __umul24(k, (uint32_t)TI_SEG) + wrap;
-}
-
-// The soft values of the step described by the depuncturing word w (dabx_spec.hpp: step_info) as the A row the matrix core wants:
-// (2 x0, 2 x1, 2 x2, 2 x3), one byte each, zero where punctured (|x| <= 31, so twice a value fits its byte).  A step keeps a prefix
-// of its four bits, so the four bytes at the step's offset are loaded unconditionally (issued together, no branch, valid addresses:
-// the buffers carry slack), shifted left by one inside their bytes, and the punctured ones are masked off.
+// MSC rows are stored residue-major (TI_SEG = 55296/16 bytes per residue class of the bit index) and per LOGICAL frame: k_demod
+// files residue class q of CIF c in the row of frame c - bitrev4(q), where its 192 bytes per symbol are contiguous (written from the
+// other side — one row per CIF, the classes picked from 16 rows here — the decoder needed a table of 16 row offsets per codeword and nine
+// address instructions per gathered step; written de-interleaved in natural bit order the writer would store single bytes 16 apart).
+// So a codeword's bit i sits at a fixed offset from the codeword's base, (i & 15) * TI_SEG + (i >> 4), and the four offsets and the byte
+// mask of every trellis step come from a table made once per profile (dabx_spec.hpp: step_gather; linear rows — FIC, stage tests — have
+// their own variant): five words per step and lane, each from an array of its own (contiguous across the wave), read a round ahead.
+constexpr int VIT_INFO_PAD = 256;                    // = dabx::kStepInfoPad: empty entries behind the end of each array
+// The soft values of a step as the A row the matrix core wants: (2 x0, 2 x1, 2 x2, 2 x3), one byte each, zero where punctured
+// (|x| <= 31, so twice a value fits its byte).  A step keeps a prefix of its four bits; all four bytes are loaded unconditionally
+// (valid addresses: the punctured ones point at the step's first bit), shifted left by one inside their bytes, and the punctured
+// ones are masked off.  Three phases, each a loop half or more apart so that none waits for the one before:
+//   gather_load   the step's record -> the four offsets and the mask
+//   gather_bytes  the four byte loads, each into the register that held its offset
+//   gather_finish the A row
 // (d16 byte loads that would drop the bytes into the halves of two registers were tried: on a GPU with SRAM ECC — this one — a d16
 // load clears the other half of its destination, so the bytes still have to be collected by instructions.)
-struct Gather { uint32_t b0, b1, b2, b3, m; };       // m: the step's byte mask (the depuncturing word itself is dead once the loads are out)
-// issue: the four byte loads of the step described by w; they stay in flight until gather_finish
-__device__ __forceinline__ void gather_issue(Gather &g, const VitSrc &src, const uint32_t *tab, int sh, uint32_t w)
+struct Gather { uint32_t b0, b1, b2, b3, m; };
+__device__ __forceinline__ void gather_load(Gather &g, const char *info, uint32_t toff, uint32_t arr_bytes)
 {
-    const uint32_t i0 = w >> 5;
-    const uint32_t *t = tab + (i0 & 15u);
-    const uint32_t q = (i0 >> 4) << sh;
-    const uint8_t *base = reinterpret_cast<const uint8_t *>(src.base);
-    g.b0 = base[t[0] + q]; g.b1 = base[t[1] + q]; g.b2 = base[t[2] + q]; g.b3 = base[t[3] + q];
-    // every byte holds a value of -31..31: shifted left by one inside its byte it is twice that value; 0xFE per kept byte
-    // clears the neighbour's sign bit that came in from below, 0 per punctured byte clears the byte
-    g.m = 0xFEFEFEFEu >> (w & 31u);
+    // info, arr_bytes: wave-uniform — five scalar bases, one 32-bit lane offset
+    g.b0 = *reinterpret_cast<const uint32_t *>(info + toff);
+    g.b1 = *reinterpret_cast<const uint32_t *>((info + arr_bytes) + toff);
+    g.b2 = *reinterpret_cast<const uint32_t *>((info + 2 * (size_t)arr_bytes) + toff);
+    g.b3 = *reinterpret_cast<const uint32_t *>((info + 3 * (size_t)arr_bytes) + toff);
+    g.m = *reinterpret_cast<const uint32_t *>((info + 4 * (size_t)arr_bytes) + toff);
 }
-// finish, a loop iteration later: the A row.  The empty asm pins the place: left alone, the compiler collects the bytes right behind
-// the loads (the round's branch made that the natural spot) and the wave waits out their whole latency there.
-__device__ __forceinline__ int gather_finish(Gather &g)
+__device__ __forceinline__ void gather_bytes(Gather &g, const uint8_t *base)
 {
-    asm volatile("" : "+v"(g.b0), "+v"(g.b1), "+v"(g.b2), "+v"(g.b3));
-    const uint32_t W = g.b0 | (g.b1 << 8) | (g.b2 << 16) | (g.b3 << 24);
-    return (int)((W << 1) & g.m);
+    g.b0 = base[g.b0]; g.b1 = base[g.b1]; g.b2 = base[g.b2]; g.b3 = base[g.b3];
+}
+// One asm statement: it pins the place (left alone, the compiler collects the bytes right behind the loads and the wave waits out
+// their whole latency there) and takes five instructions where the compiler's shifts and ors take six.  Every byte holds a value of
+// -31..31: shifted left by one inside its byte it is twice that value; 0xFE per kept byte clears the neighbour's sign bit that
+// came in from below, 0 per punctured byte clears the byte.
+__device__ __forceinline__ int gather_finish(const Gather &g)
+{
+    uint32_t lo, hi;
+    asm volatile("v_lshl_or_b32 %[lo], %[b1], 8, %[b0]\n\t"
+                 "v_lshl_or_b32 %[hi], %[b3], 8, %[b2]\n\t"
+                 "v_lshl_or_b32 %[lo], %[hi], 16, %[lo]\n\t"
+                 "v_lshlrev_b32 %[lo], 1, %[lo]\n\t"
+                 "v_and_b32 %[lo], %[lo], %[m]"
+                 : [lo] "=&v"(lo), [hi] "=&v"(hi) : [b0] "v"(g.b0), [b1] "v"(g.b1), [b2] "v"(g.b2), [b3] "v"(g.b3), [m] "v"(g.m) : "memory");
+    return (int)lo;
+}
+
+// a wave-uniform 64-bit value into scalar registers (the compiler cannot prove the uniformity of what is computed from a loaded
+// work item and otherwise re-reads it from vector registers at every use; applied to OFFSETS: a pointer rebuilt from integers
+// loses its address space and its loads become flat ones with 64-bit vector addresses)
+__device__ __forceinline__ size_t scalar_u64(size_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((size_t)hi << 32) | lo;
 }
 
 // ---- add-compare-select, hand scheduled (text generated by tools/gen_acs32.py).
@@ -1001,8 +1006,8 @@ __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int la
 #undef DABX_ACS_OPS
 
 constexpr int VIT_BLK = 48;          // trellis steps per loop iteration = two chunks of 24 (one decision word each)
-constexpr int VIT_XS = 192;          // staging ring of A rows: four iterations = THREE gather rounds of 64 steps, one step per lane
-constexpr int VIT_XS_WORDS = VIT_XS + 20;   // + the 19 entries of the gather's address table
+constexpr int VIT_XS = 192;          // staging ring of A rows: four iterations of 48 steps
+constexpr int VIT_XS_WORDS = VIT_XS;
 constexpr int VIT_RING = 16;         // decision words (24 steps each) a wave keeps in LDS: 4 KB
 constexpr int VIT_UNIT = 8;          // words decoded (or, without a merge, spilled) at a time: 192 steps = 6 output words
 
@@ -1091,12 +1096,12 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
 //           survivors of a stretch of 192 steps have not merged within another 192 (erased or tied input)
 //   prbs32: energy dispersal, bit 31-j of word h = PRBS bit 32 h + j
 //   out:    n_in/8 bytes.  nsteps (= n_in + 6), n_in and all pointers are wave-uniform.
-//   xs:     the wave's soft-value staging ring in LDS: the A rows of 192 steps (row of step t at dword t mod 192), the 19
-//           dwords of the address table behind them
+//   soft:   the codeword's first soft bit (wave-uniform); info: its gather map (dabx_spec.hpp: step_gather), linear or residue-major
+//   xs:     the wave's soft-value staging ring in LDS: the A rows of 192 steps (row of step t at dword t mod 192)
 //   SPILL:  false = the first pass (k_viterbi): a codeword whose survivors do not merge gives up (returns false, dec is not
 //           touched) and is decoded again by k_viterbi_requeue, which has a block of scratch per wave (SPILL = true)
 template <bool SPILL>
-__device__ bool viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ info, int nsteps, int n_in,
+__device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t *__restrict__ info, int nsteps, int n_in,
                              const uint32_t *__restrict__ prbs32, uint32_t *dec, uint8_t *out, int *xs, uint32_t *ring)
 {
     const int lane = threadIdx.x & 63;
@@ -1120,49 +1125,61 @@ __device__ bool viterbi_wave(const VitSrc &src, const uint32_t *__restrict__ inf
     const int nblk = nsteps / VIT_BLK;                           // full blocks of two chunks (even); the tail follows
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
     int w_dec = 0, w_ring = 0;                                   // first word not yet decoded / first word still in the ring
-    // Soft-bit pipeline.  All 64 lanes gather: round R fetches the steps 64 R .. 64 R + 63 (one per lane) into the staging ring of 192
-    // A rows, three rounds per four loop iterations of 48 steps (round R of a super-block of 192 steps at its iteration R; none at the
-    // fourth).  The depuncturing words of the round after next and the soft bytes of the next round are in flight while an iteration
-    // runs, so each of the two dependent loads has at least an iteration of ACS work to hide behind.  (Until round 3: blocks of 48
-    // steps gathered by 48 lanes, a quarter of the gather's instructions spent on idle lanes.)  Every DAB codeword is 192 k + 6 steps.
-    // Byte offset of the lane's next depuncturing word: no clamping — the tables carry kStepInfoPad zero words behind their end.
-    uint32_t toff = 4u * (uint32_t)lane;
-    const uint32_t tinc = 4u * 64u;
+    // Soft-bit pipeline.  All 64 lanes gather: round q fetches the steps 64 q .. 64 q + 63 (one per lane) into rows 64 (q mod 3) .. + 63
+    // of the staging ring of 192 A rows.  Round q is made entirely inside the loop iteration before the first one that reads its
+    // rows, iteration floor(4 q / 3) - 1 — three rounds per four iterations of 48 steps, none in the iterations 2, 6, 10, …; the rows
+    // it replaces (round q - 3) were last read an iteration or more earlier.  Inside that iteration the step's offsets and mask are
+    // loaded first (five contiguous loads across the wave), its four bytes between the two chunks, and the A row is put together
+    // behind the second chunk: every load has a chunk of 24 steps to hide behind and no register of the gather is live over the
+    // decoding or the loop edge.  (Carried over the edge — bytes in flight during the decoding, a full iteration of cover — the
+    // compiler copies all five registers at the edge, and with the round's three parts in three conditional regions it keeps two
+    // register sets and copies between them at every merge: both measured slower.  So the iteration with a round and the one
+    // without are written out as two bodies.)  Every DAB codeword is 192 k + 6 steps.
+    // No register of its own for the lane's place in a round: lane l takes the step (l ^ 32) of the round's 64, so that 4 (l ^ 32) — the ds_bpermute address the exchange of phase 5 keeps anyway — is
+    // the lane's byte offset into the arrays and into the staging ring; what moves from round to round is scalar.  No clamping: the
+    // arrays carry VIT_INFO_PAD empty entries behind their end.
+    const uint32_t lane4 = (uint32_t)lane_x32;
+    const uint32_t arr_bytes = 4u * (uint32_t)(nsteps + VIT_INFO_PAD);
     // A row of this lane: row r = the step of group r of a 24-step chunk (LDS byte address: the low 32 bits of a shared
     // pointer); the four addresses of a read (rows 0..3: six dwords apart) fall into four different LDS banks
-    const uint32_t va0 = (uint32_t)(uintptr_t)xs + 24u * (lane & 3);
-    const uint32_t *tab = reinterpret_cast<const uint32_t *>(xs) + VIT_XS;
+    const uint32_t xs_a = (uint32_t)(uintptr_t)xs;
+    const uint32_t va0 = xs_a + 24u * (lane & 3);
     const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // LDS byte address of the wave's decision ring
-    const int sh = src.slot_mask < 0 ? 4 : 0;
-    if (lane < 19) xs[VIT_XS + lane] = (int)soft_tab_entry(src, (uint32_t)lane);
     const char *infob = reinterpret_cast<const char *>(info);
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(soft);
+    typedef int __attribute__((address_space(3))) *lds_int;
     Gather ga;
-    gather_issue(ga, src, tab, sh, *reinterpret_cast<const uint32_t *>(infob + toff));
-    toff += tinc;
-    uint32_t wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
-    toff += tinc;                                                // (the word this lane loads next)
+    gather_load(ga, infob, lane4, arr_bytes);                    // round 0 (the only loads of a codeword that nothing hides)
+    gather_bytes(ga, base);
+    *reinterpret_cast<lds_int>(xs_a + lane4) = gather_finish(ga);
     uint32_t A = 0;
     for (int blk = 0; blk <= nblk; ++blk) {
         const int it = blk & 3;                                  // iteration inside the super-block of 192 steps (wave-uniform)
-        if (it != 3) {
-            // round `it`: rows 64 it .. 64 it + 63 of the ring.  They were last read two or more iterations ago, and a wave's LDS
-            // operations execute in order.  Iteration `it` reads rows 48 it .. 48 it + 47: all written by now.
-            xs[64 * it + lane] = gather_finish(ga);
-#ifndef DABX_PROBE_NOGATHER
-            gather_issue(ga, src, tab, sh, wnext);
-            wnext = *reinterpret_cast<const uint32_t *>(infob + toff);
-            toff += tinc;
-#endif
-        }
         const uint32_t va = va0 + 192u * (uint32_t)it;           // the iteration's first chunk: row 48 it
-        uint32_t bits = 0;
         if (blk == nblk) {                                       // the six tail steps: no output, from state 0 (lane 0)
+            uint32_t bits = 0;
             acs6(pm, sk, va, lane_x32, bits);
             A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
             break;
         }
-        acs24(pm, sk, va, lane_x32, ring_a + (uint32_t)(((2 * blk) & (VIT_RING - 1)) * 256 + 4 * coordA));
-        acs24(pm, sk, va + 96u, lane_x32, ring_a + (uint32_t)(((2 * blk + 1) & (VIT_RING - 1)) * 256 + 4 * coordA));
+        const uint32_t wa0 = ring_a + (uint32_t)(((2 * blk) & (VIT_RING - 1)) * 256 + 4 * coordA);
+        const uint32_t wa1 = ring_a + (uint32_t)(((2 * blk + 1) & (VIT_RING - 1)) * 256 + 4 * coordA);
+#ifndef DABX_PROBE_NOGATHER
+        if (it != 2) {
+            // round q = 3 (blk / 4) + (it + 1 or, in the last iteration of a super-block, 3)
+            const uint32_t q = 3u * (uint32_t)(blk >> 2) + (it == 3 ? 3u : (uint32_t)it + 1u);
+            const uint32_t slot = it == 3 ? 0u : (uint32_t)it + 1u;               // q mod 3
+            gather_load(ga, infob, lane4 + 256u * q, arr_bytes);
+            acs24(pm, sk, va, lane_x32, wa0);
+            gather_bytes(ga, base);
+            acs24(pm, sk, va + 96u, lane_x32, wa1);
+            *reinterpret_cast<lds_int>(xs_a + 256u * slot + lane4) = gather_finish(ga);
+        } else
+#endif
+        {
+            acs24(pm, sk, va, lane_x32, wa0);
+            acs24(pm, sk, va + 96u, lane_x32, wa1);
+        }
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
 #ifdef DABX_PROBE_NOTRACE
@@ -1201,17 +1218,26 @@ __device__ __forceinline__ bool viterbi_item(const DevCtx &C, const DevWork &w, 
 {
     const DevState &st = C.state[w.stream];
     if (st.acq_fail) return true;
+    // one call for both kinds of codeword (one copy of the decoder in the kernel): everything that differs is an argument
+    const int8_t *soft;
+    const uint32_t *info;
+    uint8_t *out;
+    int nsteps, n_in;
     if (w.sub < 0) {
-        VitSrc src = {C.fic_soft + ((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304, 0, -1};
-        uint8_t *out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
-        return viterbi_wave<SPILL>(src, C.stepinfo + C.fic_info_off, 774, 768, C.prbs, dec, out, xs, ring);
+        soft = C.fic_soft + scalar_u64(((size_t)w.stream * C.max_frames + w.frame) * FICBITS + w.c * 2304);
+        out = C.fib + (((size_t)w.stream * C.max_frames + w.frame) * 12 + 3 * w.c) * 32;
+        info = C.stepinfo + C.fic_info_off; nsteps = 774; n_in = 768;
+    } else {
+        const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
+        const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
+        if (r < 0) return true;                      // time de-interleaver still filling (k_finish flags it)
+        // the row of logical frame r (k_demod files every residue class where it belongs); sub-channels start on 64-bit boundaries,
+        // so start_bit >> 4 is the sub-channel's place inside each of the row's 16 residue segments
+        soft = C.ti + scalar_u64(((size_t)w.stream * C.ti_slots + (size_t)(r & (C.ti_slots - 1))) * CIFBITS + (sc.start_bit >> 4));
+        out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
+        info = C.stepinfo + sc.info_off; nsteps = sc.nsteps; n_in = sc.n_in;
     }
-    const DevSub &sc = C.sub[(size_t)w.stream * 64 + w.sub];
-    const int64_t r = st.cif + 4 * (int64_t)w.frame + w.c - 15;
-    if (r < 0) return true;                          // time de-interleaver still filling (k_finish flags it)
-    VitSrc src = {C.ti + (size_t)w.stream * C.ti_slots * CIFBITS + (sc.start_bit >> 4), r, C.ti_slots - 1};
-    uint8_t *out = C.msc + (((size_t)w.stream * C.max_frames + w.frame) * 4 + w.c) * (size_t)C.msc_stride + sc.out_off;
-    return viterbi_wave<SPILL>(src, C.stepinfo + sc.info_off, sc.nsteps, sc.n_in, C.prbs, dec, out, xs, ring);
+    return viterbi_wave<SPILL>(soft, info, nsteps, n_in, C.prbs, dec, out, xs, ring);
 }
 
 __global__ __launch_bounds__(256) void k_viterbi(DevCtx C, const DevWork *__restrict__ work, int n_work)
@@ -1268,8 +1294,7 @@ __global__ __launch_bounds__(256) void k_viterbi_linear(const int8_t *soft, int 
     if (wi >= n_cw) return;
     __shared__ __attribute__((aligned(16))) int xs_all[4][VIT_XS_WORDS];
     __shared__ __attribute__((aligned(256))) uint32_t ring_all[4][VIT_RING * 64];     // survivors_merged() relies on the alignment
-    VitSrc src = {soft + (size_t)wi * n_coded, 0, -1};
-    (void)viterbi_wave<true>(src, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
+    (void)viterbi_wave<true>(soft + (size_t)wi * n_coded, info, nsteps, n_in, prbs, scratch + (size_t)wi * ((nsteps / 24 + 1) * 64), out + (size_t)wi * (n_in / 8), xs_all[wave], ring_all[wave]);
 }
 
 // stage-level FFT: one workgroup per vector, natural order in and out

@@ -205,27 +205,37 @@ inline bool any_profile(int option, int level, int kbps, Profile &p)
     return option == 2 ? uep_profile(level, p) : eep_profile(option, level, kbps, p);
 }
 
-// depuncturing map: per trellis step, (offset of its first kept bit << 5) | 8 * (4 - number of kept bits).  Every
-// puncturing vector of EN 300 401 table 29 keeps a PREFIX of the four mother-code bits of a step (1000, 1100, 1110 or
-// 1111), so the kept soft bits are the next `ones` bits of the stream and the low field is the right shift that turns
-// 0xFFFFFFFF into their byte mask.
+// Gather map of a codeword: for every trellis step the byte offsets of its four soft bits from the codeword's base and the byte mask
+// of the ones it keeps — five arrays of steps() + kStepInfoPad words, one behind the other (offsets of bit 0, 1, 2, 3, masks), so that the
+// 64 lanes of a wave read each of them with one contiguous load.  Every puncturing vector of EN 300 401 table 29 keeps a PREFIX of the
+// four mother-code bits of a step (1000, 1100, 1110 or 1111), so the kept soft bits are the next `ones` bits of the stream; the
+// offsets of the punctured ones point at the step's first bit (a valid address: the kernel loads all four and masks).
+//   linear:  coded bit i at byte i (FIC rows, the stage-level entry point)
+//   !linear: the MSC row of a logical frame, residue-major (dabx_dev.h): bit i at (i & 15) * kTiSeg + (i >> 4) from the
+//            sub-channel's place in residue class 0
+// The mask is 0xFE per kept byte (the kernel doubles the values inside their bytes: the bit that comes in from below is cleared).
+// Entries [steps() ..] of every array: what k_viterbi's fetch reads for the steps past the end (it runs up to two rounds of 64 steps
+// ahead and does not clamp its index): offset 0, mask 0.
 constexpr int kStepInfoPad = 256;
-inline std::vector<uint32_t> step_info(const Profile &p)
+constexpr int kStepArrays = 5;
+constexpr int kTiSeg = kCifBits / 16;
+inline std::vector<uint32_t> step_gather(const Profile &p, bool linear)
 {
-    std::vector<uint32_t> info;
-    info.reserve(p.steps() + kStepInfoPad);
-    uint32_t off = 0;
+    const size_t n = static_cast<size_t>(p.steps() + kStepInfoPad);
+    std::vector<uint32_t> info(n * kStepArrays, 0u);
+    uint32_t bit = 0;
+    size_t step = 0;
+    auto place = [&](uint32_t i) { return linear ? i : (i & 15u) * static_cast<uint32_t>(kTiSeg) + (i >> 4); };
     auto emit = [&](int ones) {
-        info.push_back((off << 5) | static_cast<uint32_t>(8 * (4 - ones)));
-        off += ones;
+        for (int j = 0; j < 4; ++j) info[static_cast<size_t>(j) * n + step] = place(bit + static_cast<uint32_t>(j < ones ? j : 0));
+        info[4 * n + step] = 0xFEFEFEFEu >> (8 * (4 - ones));
+        bit += static_cast<uint32_t>(ones);
+        ++step;
     };
     for (int s = 0; s < p.nseg; ++s)
         for (int blk = 0; blk < p.L[s]; ++blk)
             for (int g = 0; g < 32; ++g) emit(punct_group_ones(p.PI[s], g & 7));
     for (int g = 0; g < 6; ++g) emit(2);
-    // words [steps() ..]: what k_viterbi's fetch reads for the steps past the end (its fetch runs up to three blocks of 48 ahead and
-    // does not clamp its index; the lanes without a step to fetch read word steps() + lane): nothing to load
-    info.insert(info.end(), kStepInfoPad, 0u);
     return info;
 }
 
