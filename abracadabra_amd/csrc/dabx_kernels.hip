@@ -983,27 +983,28 @@ __device__ __forceinline__ size_t scalar_u64(size_t v)
 // kernel.  The A operands are the packed soft values of the chunk, staged in LDS memory by the lanes that gathered
 // them: lane l reads the row of group l mod 4.
 #include "dabx_acs32.inc"
-#define DABX_ACS_OPS                                                                                                \
-    : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D)                                    \
+#define DABX_ACS_IN                                                                                                 \
     : [va] "v"(va), [ad] "v"(lane_x32), [wa] "v"(wa), [k0] "v"(sk[0]), [k1] "v"(sk[1]), [k2] "v"(sk[2]),            \
       [k3] "v"(sk[3]), [k4] "v"(sk[4]), [k5] "v"(sk[5]), [m128] "s"(-128)                                           \
     : "memory", DABX_ACS_CLOBBER
 // four groups = 24 steps = one decision word, written byte by byte to the LDS address wa; va = LDS byte address of the lane's
-// A row: the chunk's first dword + 24 (lane & 3)
+// A row: the chunk's first dword + 24 (lane & 3).  SECOND: the second chunk of a loop iteration, with the first chunk's va and wa
+// (its rows lie 96 bytes further, its decision word one row of 256 bytes further: immediate offsets).
+template <bool SECOND = false>
 __device__ __forceinline__ void acs24(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t wa)
 {
     int S, K, D;
-    uint32_t bits = 0;
-    asm volatile(DABX_ACS24_TEXT DABX_ACS_OPS);
+    if (SECOND) asm volatile(DABX_ACS24B_TEXT : [pm] "+v"(pm), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D) DABX_ACS_IN);
+    else asm volatile(DABX_ACS24_TEXT : [pm] "+v"(pm), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D) DABX_ACS_IN);
 }
 // one group of six steps (the tail of a codeword): only row 0 of the results is used
 __device__ __forceinline__ void acs6(int &pm, const int *sk, uint32_t va, int lane_x32, uint32_t &bits)
 {
     int S, K, D;
     const uint32_t wa = 0;
-    asm volatile(DABX_ACS6_TEXT DABX_ACS_OPS);
+    asm volatile(DABX_ACS6_TEXT : [pm] "+v"(pm), [bits] "+v"(bits), [S] "=&v"(S), [K] "=&v"(K), [D] "=&v"(D) DABX_ACS_IN);
 }
-#undef DABX_ACS_OPS
+#undef DABX_ACS_IN
 
 constexpr int VIT_BLK = 48;          // trellis steps per loop iteration = two chunks of 24 (one decision word each)
 constexpr int VIT_XS = 192;          // staging ring of A rows: four iterations of 48 steps
@@ -1144,7 +1145,7 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
     // pointer); the four addresses of a read (rows 0..3: six dwords apart) fall into four different LDS banks
     const uint32_t xs_a = (uint32_t)(uintptr_t)xs;
     const uint32_t va0 = xs_a + 24u * (lane & 3);
-    const uint32_t ring_a = (uint32_t)(uintptr_t)ring;           // LDS byte address of the wave's decision ring
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)ring + ((uint32_t)coordA << 2);      // LDS byte address of the lane's word in row 0 of the wave's decision ring
     const char *infob = reinterpret_cast<const char *>(info);
     const uint8_t *base = reinterpret_cast<const uint8_t *>(soft);
     typedef int __attribute__((address_space(3))) *lds_int;
@@ -1162,8 +1163,8 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
             A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
             break;
         }
-        const uint32_t wa0 = ring_a + (uint32_t)(((2 * blk) & (VIT_RING - 1)) * 256 + 4 * coordA);
-        const uint32_t wa1 = ring_a + (uint32_t)(((2 * blk + 1) & (VIT_RING - 1)) * 256 + 4 * coordA);
+        // (word 2 blk is even: the iteration's second word is the next row of the ring, never across its end)
+        const uint32_t wa0 = ring_lane + (uint32_t)(((2 * blk) & (VIT_RING - 1)) * 256);
 #ifndef DABX_PROBE_NOGATHER
         if (it != 2) {
             // round q = 3 (blk / 4) + (it + 1 or, in the last iteration of a super-block, 3)
@@ -1172,13 +1173,13 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
             gather_load(ga, infob, lane4 + 256u * q, arr_bytes);
             acs24(pm, sk, va, lane_x32, wa0);
             gather_bytes(ga, base);
-            acs24(pm, sk, va + 96u, lane_x32, wa1);
+            acs24<true>(pm, sk, va, lane_x32, wa0);
             *reinterpret_cast<lds_int>(xs_a + 256u * slot + lane4) = gather_finish(ga);
         } else
 #endif
         {
             acs24(pm, sk, va, lane_x32, wa0);
-            acs24(pm, sk, va + 96u, lane_x32, wa1);
+            acs24<true>(pm, sk, va, lane_x32, wa0);
         }
         // ---- decode what can be decoded: the ring holds the words [w_ring, w_hi)
         const int w_hi = 2 * blk + 2, pend = w_hi - w_ring;
