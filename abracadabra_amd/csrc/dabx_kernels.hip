@@ -1047,8 +1047,10 @@ __device__ __forceinline__ void trace_words(const uint32_t *ring, const uint32_t
     for (int w = w_hi - 4; w >= w_lo; w -= 4) {
         uint32_t wd[4];
         if (w >= w_ring) {
+            // w is a multiple of four and so is the ring's length: the four rows are consecutive — one address, immediate offsets
+            const uint32_t *row = ring + (w & (VIT_RING - 1)) * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wd[k] = ring[((w + k) & (VIT_RING - 1)) * 64 + lane];
+            for (int k = 0; k < 4; ++k) wd[k] = row[64 * k];
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) wd[k] = dec[(w + k) * 64 + lane];
