@@ -1156,15 +1156,9 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
     gather_bytes(ga, base);
     *reinterpret_cast<lds_int>(xs_a + lane4) = gather_finish(ga);
     uint32_t A = 0;
-    for (int blk = 0; blk <= nblk; ++blk) {
+    for (int blk = 0; blk < nblk; ++blk) {
         const int it = blk & 3;                                  // iteration inside the super-block of 192 steps (wave-uniform)
         const uint32_t va = va0 + 192u * (uint32_t)it;           // the iteration's first chunk: row 48 it
-        if (blk == nblk) {                                       // the six tail steps: no output, from state 0 (lane 0)
-            uint32_t bits = 0;
-            acs6(pm, sk, va, lane_x32, bits);
-            A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
-            break;
-        }
         // (word 2 blk is even: the iteration's second word is the next row of the ring, never across its end)
         const uint32_t wa0 = ring_lane + (uint32_t)(((2 * blk) & (VIT_RING - 1)) * 256);
 #ifndef DABX_PROBE_NOGATHER
@@ -1202,6 +1196,11 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
                 w_ring = B;
             }
         }
+    }
+    {   // the six tail steps (rows 0..5 of the staging ring: nblk is a multiple of four): no output, from state 0 (lane 0)
+        uint32_t bits = 0;
+        acs6(pm, sk, va0, lane_x32, bits);
+        A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
     }
 #ifndef DABX_PROBE_NOTRACE
     trace_words(ring, dec, w_ring, w_dec, 2 * nblk, A, out32, prbs32, lane);
