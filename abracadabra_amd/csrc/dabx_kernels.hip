@@ -1076,9 +1076,9 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
         asm volatile("ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 23, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
                      "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 15, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
                      "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 7, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
-                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %[x], 1, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2"
-                     : [a] "+v"(a), [x] "=&v"(x) : [m] "s"(0xFC) : "memory");
-        a += (uint32_t)(((w - 1) & (VIT_RING - 1)) - (w & (VIT_RING - 1))) * 256u;      // to the row of the word before
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %[x], 1, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "v_lshl_add_u32 %[a], %[d], 8, %[a]"                                 // to the row of the word before (in the statement: outside it the compiler adds into a new register and copies back)
+                     : [a] "+v"(a), [x] "=&v"(x) : [m] "s"(0xFC), [d] "s"(((w - 1) & (VIT_RING - 1)) - (w & (VIT_RING - 1))) : "memory");
     }
     uint32_t P = a >> 2;
     P &= 63u;
