@@ -1041,12 +1041,14 @@ __device__ __forceinline__ uint32_t walk96(const uint32_t wd[4], uint32_t A, uin
 
 // Decode the words [w_lo, w_hi) (multiples of 4) backwards from position A at the end of word w_hi - 1.  Words from
 // w_ring on are in the wave's LDS ring, older ones (spilled because no merge was found in time) in global scratch.
+// (SPILL = false, the first pass: nothing is ever spilled, every word is in the ring)
+template <bool SPILL>
 __device__ __forceinline__ void trace_words(const uint32_t *ring, const uint32_t *dec, int w_ring, int w_lo, int w_hi, uint32_t A,
                                             uint32_t *out32, const uint32_t *__restrict__ prbs32, int lane)
 {
     for (int w = w_hi - 4; w >= w_lo; w -= 4) {
         uint32_t wd[4];
-        if (w >= w_ring) {
+        if (!SPILL || w >= w_ring) {
             // w is a multiple of four and so is the ring's length: the four rows are consecutive — one address, immediate offsets
             const uint32_t *row = ring + (w & (VIT_RING - 1)) * 64 + lane;
 #pragma unroll
@@ -1156,6 +1158,7 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
     gather_bytes(ga, base);
     *reinterpret_cast<lds_int>(xs_a + lane4) = gather_finish(ga);
     uint32_t A = 0;
+    bool gave_up = false;
     for (int blk = 0; blk < nblk; ++blk) {
         const int it = blk & 3;                                  // iteration inside the super-block of 192 steps (wave-uniform)
         const uint32_t va = va0 + 192u * (uint32_t)it;           // the iteration's first chunk: row 48 it
@@ -1182,28 +1185,31 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
 #ifdef DABX_PROBE_NOTRACE
         if (false) {
 #else
-        if (pend >= VIT_UNIT + 2 && !(pend & 1)) {               // 48, 96, 144, 192 steps after the unit's end
+        if (pend >= VIT_UNIT + 2) {                              // 48, 96, 144, 192 steps after the unit's end (pend is even)
 #endif
             const int B = w_ring + VIT_UNIT;
             uint32_t O;
             if (survivors_merged(ring, w_hi, B, coordA, O)) {
-                trace_words(ring, dec, w_ring, w_dec, B, O, out32, prbs32, lane);
+                trace_words<SPILL>(ring, dec, w_ring, w_dec, B, O, out32, prbs32, lane);
                 w_dec = w_ring = B;
-            } else if (pend == VIT_RING) {                       // no merge and the ring is full: the unit goes to global scratch
-                if (!SPILL) return false;
+            } else if (pend == VIT_RING) {                       // no merge and the ring is full
+                if (!SPILL) { gave_up = true; blk = nblk; }      // first pass: the codeword is decoded again by k_viterbi_requeue (the loop ends by its own condition: a second way out of it costs every iteration)
+                else {                                           // the unit goes to global scratch
 #pragma unroll
-                for (int k = 0; k < VIT_UNIT; ++k) dec[(w_ring + k) * 64 + lane] = ring[((w_ring + k) & (VIT_RING - 1)) * 64 + lane];
-                w_ring = B;
+                    for (int k = 0; k < VIT_UNIT; ++k) dec[(w_ring + k) * 64 + lane] = ring[((w_ring + k) & (VIT_RING - 1)) * 64 + lane];
+                    w_ring = B;
+                }
             }
         }
     }
+    if (!SPILL && gave_up) return false;
     {   // the six tail steps (rows 0..5 of the staging ring: nblk is a multiple of four): no output, from state 0 (lane 0)
         uint32_t bits = 0;
         acs6(pm, sk, va0, lane_x32, bits);
         A = ~((uint32_t)__builtin_amdgcn_readlane((int)bits, 0) >> 26);
     }
 #ifndef DABX_PROBE_NOTRACE
-    trace_words(ring, dec, w_ring, w_dec, 2 * nblk, A, out32, prbs32, lane);
+    trace_words<SPILL>(ring, dec, w_ring, w_dec, 2 * nblk, A, out32, prbs32, lane);
 #endif
     return true;
 }
