@@ -1190,7 +1190,20 @@ __device__ __forceinline__ bool viterbi_wave(const int8_t *soft, const uint32_t 
             const int B = w_ring + VIT_UNIT;
             uint32_t O;
             if (survivors_merged(ring, w_hi, B, coordA, O)) {
-                trace_words<SPILL>(ring, dec, w_ring, w_dec, B, O, out32, prbs32, lane);
+                if (!SPILL) {
+                    // first pass: exactly the unit's VIT_UNIT words, all in the ring (w_dec == w_ring): two walks of 96 steps, no loop
+                    uint32_t P = O;
+#pragma unroll
+                    for (int u = VIT_UNIT / 4 - 1; u >= 0; --u) {
+                        const int w = w_ring + 4 * u;
+                        const uint32_t *row = ring + (w & (VIT_RING - 1)) * 64 + lane;
+                        uint32_t wd[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wd[k] = row[64 * k];
+                        P = walk96(wd, P, out32, prbs32, w >> 2, lane);
+                    }
+                } else
+                    trace_words<SPILL>(ring, dec, w_ring, w_dec, B, O, out32, prbs32, lane);
                 w_dec = w_ring = B;
             } else if (pend == VIT_RING) {                       // no merge and the ring is full
                 if (!SPILL) { gave_up = true; blk = nblk; }      // first pass: the codeword is decoded again by k_viterbi_requeue (the loop ends by its own condition: a second way out of it costs every iteration)
