@@ -6,10 +6,10 @@
 // (stream, frame):
 //   k_null_search  frame acquisition on raw sample energy            (integer)
 //   k_sync         guard-interval CFO + PRS impulse-response timing  (integer + f32)
-//   k_demod        2048-point FFT, pi/4-DQPSK demap, frequency de-interleave -> int8
-//   k_viterbi      time de-interleave gather, depuncture, K=7 Viterbi, de-dispersal
+//   k_demod        2048-point FFT, pi/4-DQPSK demap, frequency and time de-interleave -> int8
+//   k_viterbi      depuncturing gather, K=7 Viterbi, de-dispersal
 //   k_finish       FIB CRC-16 and per-stream tracking state
-// No MFMA GEMM anywhere (nothing here is a contraction): the FFT is bound by its LDS exchanges, the Viterbi by VALU
+// No MFMA GEMM anywhere (nothing here is a contraction): the FFT is bound by vector issue and its LDS exchanges, the Viterbi by VALU
 // issue.  The matrix core appears once, as a sign-combination engine: six v_mfma_i32_4x4x4_16b_i8 per 24 trellis steps
 // form the branch metrics of k_viterbi so that the vector ALU is left with three instructions per step.
 //
@@ -883,8 +883,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
 // lanes that differ by one fixed xor vector of the cycle {1,2,7,8,16,32}:
 // four of the six exchanges are a DPP modifier of the max, two go through the LDS
 // crossbar (ds_swizzle / ds_bpermute).  LDS MEMORY holds what is not exchanged: the
-// block's soft values (the A rows of the MFMAs), the 19-entry address table of the
-// gather and the ring of decision words the merge test and the traceback walk.
+// block's soft values (the A rows of the MFMAs) and the ring of decision words the merge
+// test and the traceback walk.
 namespace {
 
 // (the xor vectors of the six phases: 1, 2, 7, 8, 16, 32 — quad_perm, quad_perm, row_half_mirror, row_ror:8 as DPP
