@@ -730,6 +730,14 @@ __global__ __launch_bounds__(256, 4) void k_sync(DevCtx C, int n_frames)
 // ------------------------------------------------------------------------ demod
 // One workgroup per (stream, frame, group of 19 symbols).  The previous symbol's
 // spectrum stays in registers (same thread owns the same bins in every symbol).
+// FFT output slot e of thread t holds bin b0(t) + 64 (e >> 2) + 512 (e & 3) with b0(t) in 0..447 (dabx_spec.hpp: bin_of_pos(8 t + e)):
+// the slots whose 448 bins all are carriers (1..768 or 1280..2047) need no mask in the demapper's sum
+constexpr bool slot_always_carrier(int e)
+{
+    const int lo = 64 * (e >> 2) + 512 * (e & 3), hi = lo + 447;
+    return (lo >= 1 && hi <= 768) || (lo >= 1280 && hi <= 2047);
+}
+static_assert(!slot_always_carrier(0) && slot_always_carrier(3) && slot_always_carrier(4) && slot_always_carrier(7), "bin_of_pos");
 constexpr int DEMOD_GROUPS = 4, DEMOD_GSYMS = 19;          // (2 x 38 and 1 x 76 symbols per workgroup run at the same speed)
 
 // SCO: the variant that de-rotates the differential product for streams whose sampling clock is off (below).  Both
@@ -825,7 +833,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
             for (int e = 0; e < 8; ++e) {
                 if constexpr (SCO) { const float2 r = rt_l[t]; y[e] = cmul(cmul(y[e], sm[e]), (cf){r.x, r.y}); }
                 const float a = fabsf(y[e].x) + fabsf(y[e].y);
-                acc = acc + ((used >> e) & 1u ? a : 0.0f);               // adding +0 leaves the sum as it is
+                if (slot_always_carrier(e)) acc = acc + a;               // (three of the eight slots: no select)
+                else acc = acc + ((used >> e) & 1u ? a : 0.0f);          // adding +0 leaves the sum as it is
             }
             float S = reduce256(acc, red, t), gsc = 0.0f;
             if (S > 0.0f && S < __builtin_inff()) { int E; frexpf(S, &E); gsc = ldexpf(1.0f, SOFT_EXP - E); }
@@ -863,8 +872,8 @@ __global__ __launch_bounds__(256, 4) void k_demod(DevCtx C, int n_frames)
                     // longer depend on the frame (k_viterbi reads them from a table made once per profile).
                     const int res = t / 6, part = t % 6;
                     const int64_t frame = cif0 + (l - 4) / 18 - (int64_t)(__builtin_bitreverse32((uint32_t)res) >> 28);
-                    int8_t *row = ti + (size_t)(frame & (C.ti_slots - 1)) * CIFBITS;
-                    dst = row + res * TI_SEG + ((l - 4) % 18) * (SYMBITS / 16) + 16 * part;
+                    // (32-bit arithmetic: at most 256 rows of 55296 bytes)
+                    dst = ti + ((uint32_t)(frame & (C.ti_slots - 1)) * (uint32_t)CIFBITS + (uint32_t)(res * TI_SEG + ((l - 4) % 18) * (SYMBITS / 16) + 16 * part));
                     imoff = NCAR / 16;
                 }
                 *reinterpret_cast<uint4 *>(dst) = re;
