@@ -1346,16 +1346,27 @@ __global__ __launch_bounds__(256) void k_finish(DevCtx C, int n_frames)
 {
     const int s = blockIdx.x, t = threadIdx.x;
     DevState &st = C.state[s];
+    // the frames' synchronisation records for the tracker below, fetched by one thread each while the others check FIBs (read one
+    // after the other by the thread that runs the tracker they were a chain of memory round trips)
+    __shared__ int64_t sh_t0[64];
+    __shared__ int32_t sh_flags[64], sh_inc[64];
+    if (t < n_frames) {
+        const DevSync &r = C.sync[(size_t)s * C.max_frames + t];
+        sh_t0[t] = r.t_sym0; sh_flags[t] = r.flags; sh_inc[t] = r.inc;
+    }
     for (int k = t; k < n_frames * 12; k += 256) {
         const uint8_t *fb = C.fib + ((size_t)s * C.max_frames * 12 + k) * 32;
+        const uint4 w0 = reinterpret_cast<const uint4 *>(fb)[0], w1 = reinterpret_cast<const uint4 *>(fb)[1];      // the FIB in two loads
+        const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         uint32_t crc = 0xFFFF;
+#pragma unroll
         for (int i = 0; i < 30; ++i) {
-            crc ^= (uint32_t)fb[i] << 8;
+            crc ^= ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu) << 8;
 #pragma unroll
             for (int b = 0; b < 8; ++b) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
         }
         crc = ~crc & 0xFFFF;
-        C.fib_ok[(size_t)s * C.max_frames * 12 + k] = (!st.acq_fail && crc == (((uint32_t)fb[30] << 8) | fb[31])) ? 1 : 0;
+        C.fib_ok[(size_t)s * C.max_frames * 12 + k] = (!st.acq_fail && crc == ((((w[7] >> 16) & 0xFFu) << 8) | (w[7] >> 24))) ? 1 : 0;
     }
     for (int k = t; k < n_frames * 4; k += 256)
         C.msc_valid[(size_t)s * C.max_frames * 4 + k] = (!st.acq_fail && st.cif + k - 15 >= 0) ? 1 : 0;
@@ -1377,10 +1388,10 @@ __global__ __launch_bounds__(256) void k_finish(DevCtx C, int n_frames)
         int64_t e_first = 0, e_last = 0;
         int f_first = -1, f_last = -1;
         for (int f = 0; f < n_frames; ++f) {
-            const DevSync &r = C.sync[(size_t)s * C.max_frames + f];
-            nbad = (r.flags & 1) ? 0 : nbad + 1;
-            if (r.flags & 1) {
-                const int64_t e = r.t_sym0 + BACKOFF - TG - TNULL - (st.pos + (int64_t)f * TF + (((int64_t)f * slope0) >> 16));
+            const int32_t flags = sh_flags[f];
+            nbad = (flags & 1) ? 0 : nbad + 1;
+            if (flags & 1) {
+                const int64_t e = sh_t0[f] + BACKOFF - TG - TNULL - (st.pos + (int64_t)f * TF + (((int64_t)f * slope0) >> 16));
                 if (f_first < 0) { f_first = f; e_first = e; }
                 f_last = f; e_last = e;
             }
@@ -1391,10 +1402,9 @@ __global__ __launch_bounds__(256) void k_finish(DevCtx C, int n_frames)
         if (!wide && f_last >= 0) sl += (int32_t)(((e_last * 65536) / (f_last + 1)) / 4);
         else if (wide && f_last > f_first) sl = (int32_t)(((e_last - e_first) * 65536) / (f_last - f_first));
         sl = min(max(sl, -SLOPE_MAX), SLOPE_MAX);
-        const DevSync &last = C.sync[(size_t)s * C.max_frames + n_frames - 1];
         st.slope = sl;
-        st.pos = last.t_sym0 + BACKOFF - TG - TNULL + TF + (sl >> 16);
-        st.inc = last.inc;
+        st.pos = sh_t0[n_frames - 1] + BACKOFF - TG - TNULL + TF + (sl >> 16);
+        st.inc = sh_inc[n_frames - 1];
         st.cif += 4 * (int64_t)n_frames;
         st.bad = nbad;
         st.locked = wide ? (nbad == 0) : (nbad < 4);
