@@ -959,7 +959,7 @@ __device__ __forceinline__ int gather_finish(const Gather &g)
     asm volatile("v_lshl_or_b32 %[lo], %[b1], 8, %[b0]\n\t"
                  "v_lshl_or_b32 %[hi], %[b3], 8, %[b2]\n\t"
                  "v_lshl_or_b32 %[lo], %[hi], 16, %[lo]\n\t"
-                 "v_lshlrev_b32 %[lo], 1, %[lo]\n\t"
+                 "v_add_u32 %[lo], %[lo], %[lo]\n\t"                 // << 1 as an add: full rate, the shift is not
                  "v_and_b32 %[lo], %[lo], %[m]"
                  : [lo] "=&v"(lo), [hi] "=&v"(hi) : [b0] "v"(g.b0), [b1] "v"(g.b1), [b2] "v"(g.b2), [b3] "v"(g.b3), [m] "v"(g.m) : "memory");
     return (int)lo;
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ bool survivors_merged(const uint32_t *ring, int w_hi,
         asm volatile("ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 23, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
                      "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 15, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
                      "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %[x], 7, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
-                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %[x], 1, %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
+                     "ds_read_b32 %[x], %[a]\n\ts_waitcnt lgkmcnt(0)\n\tv_add_u32 %[x], %[x], %[x]\n\tv_bitop3_b32 %[a], %[a], %[x], %[m] bitop3:0xd2\n\t"
                      "v_lshl_add_u32 %[a], %[d], 8, %[a]"                                 // to the row of the word before (in the statement: outside it the compiler adds into a new register and copies back)
                      : [a] "+v"(a), [x] "=&v"(x) : [m] "s"(0xFC), [d] "s"(((w - 1) & (VIT_RING - 1)) - (w & (VIT_RING - 1))) : "memory");
     }
